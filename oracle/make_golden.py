@@ -1,0 +1,339 @@
+"""Generate golden vectors by importing and running the reference itself (CPU, this container only).
+
+Usage:  cd /root/repo && PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+The reference (read-only at /root/reference) is imported unmodified; the one package it needs that
+is not installed here (tensorboard) is replaced by an empty stand-in module before the import, which
+is touched only inside ``fit()``.  Outputs are small ``.npz`` files of inputs and expected outputs
+under ``tests/golden/``; no reference source is copied.  The GPU box never runs this script.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+stub = types.ModuleType("torch.utils.tensorboard")
+stub.SummaryWriter = object
+sys.modules["torch.utils.tensorboard"] = stub
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+from src.vae_models import CVAE                      # noqa: E402
+from src.conditioning_lib import Conditioner         # noqa: E402
+from src import testing_lib, imputation_lib, utils as ref_utils   # noqa: E402
+
+torch.autograd.set_detect_anomaly(False)
+torch.set_num_threads(8)
+
+
+def tiny_model_cfg(lik="dict-gauss", H=32, L=5, V=9, nh=2):
+    post = {"dist_type": "normal", "learn_sigma": True, "sigma_lim": 0.05, "total_max_std": 3.0,
+            "mu_upper_lim": 5.0, "mu_lower_lim": -5.0, "num_neurons": H, "num_hidden_layers": nh,
+            "dropout": False, "dropout_rate": 0.2, "batch_normalization": True, "resnet": False}
+    if lik == "dict-gauss":
+        like = {"dist_type": "dict-gauss", "vocab_size": V, "learn_sigma": True, "sigma_lim": 1e-4,
+                "marginal_std_lim": 0.1, "total_max_std": 6.0, "mu_upper_lim": 5.0, "mu_lower_lim": -3,
+                "num_neurons": H, "num_hidden_layers": nh, "dropout": False, "dropout_rate": 0.2,
+                "batch_normalization": True, "resnet": False}
+    else:
+        like = {"dist_type": "normal", "learn_sigma": True, "sigma_lim": 0.1, "mu_upper_lim": 5.0,
+                "mu_lower_lim": -3, "num_neurons": H, "num_hidden_layers": nh, "dropout": False,
+                "batch_normalization": True}
+    return {"latent_dim": L, "distribution_dict": {"posterior": post, "likelihood": like}}
+
+
+def make_conditioner(n, rng):
+    months = rng.integers(1, 13, size=(n, 1))
+    weekdays = rng.integers(0, 7, size=(n, 1))
+    cset = {"months": months, "weekdays": weekdays}
+    cond = Conditioner(tags=["months", "weekdays"], supports=[list(range(1, 13)), list(range(7))],
+                       types=["circ", "circ"], condition_set=cset)
+    return cond, cset
+
+
+def synth_profiles(n, d, rng):
+    x = np.clip(rng.normal(1.0, 1.0, size=(n, d)), -3, 5)
+    x[rng.random((n, d)) < 0.1] = -3.0
+    return x.astype(np.float32)
+
+
+def np_state(sd):
+    return {"sd::" + k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+class Cdim:
+    def __init__(self, c): self.cond_dim = c
+
+
+def case_forward_train(name, lik, seed, D=6, C=4, B=8, S=3, three_d=False, steps=4):
+    rng = np.random.default_rng(seed)
+    cfg = tiny_model_cfg(lik)
+    torch.manual_seed(seed)
+    model = CVAE(input_dim=D, conditioner=Cdim(C), **cfg)
+    L = cfg["latent_dim"]
+    out = {"model_cfg": json.dumps(cfg), "D": D, "C": C, "B": B, "S": S}
+    out.update(np_state(model.state_dict()))
+    x = torch.tensor(synth_profiles(B, D, rng))
+    if three_d:
+        c = torch.tensor(rng.normal(size=(B, S, C)).astype(np.float32))
+    else:
+        c = torch.tensor(rng.normal(size=(B, C)).astype(np.float32))
+    out["x"], out["c"] = x.numpy(), c.numpy()
+
+    # forward + loss in train and eval mode with captured eps
+    for mode in ("train", "eval"):
+        # fresh copy so train-mode BN updates do not leak between the two
+        torch.manual_seed(seed)
+        m2 = CVAE(input_dim=D, conditioner=Cdim(C), **cfg)
+        m2.load_state_dict(model.state_dict())
+        m2.train() if mode == "train" else m2.eval()
+        torch.manual_seed(seed + 100)
+        eps = torch.randn((S, B, L)) if not three_d else torch.randn((1, S, B, L))
+        torch.manual_seed(seed + 100)
+        xd, zd = m2.forward(x, c, num_mc_samples=S)
+        loss = m2.loss(x, xd["params"], zd["params"], beta=0.7, prior_params=m2.prior_params)
+        out[f"{mode}_eps"] = eps.reshape(S, B, L).numpy()
+        out[f"{mode}_lik_mu"] = xd["params"]["mu"].detach().numpy()
+        out[f"{mode}_lik_sigma"] = xd["params"]["sigma"].detach().numpy()
+        out[f"{mode}_post_mu"] = zd["params"]["mu"].detach().numpy()
+        out[f"{mode}_post_sigma"] = zd["params"]["sigma"].detach().numpy()
+        out[f"{mode}_z"] = zd["samples"].detach().numpy()
+        out[f"{mode}_rll_rows"] = m2.reconstruction_loglikelihood(x, xd["params"]).detach().numpy()
+        for k in ("loss", "elbo", "rll", "kl"):
+            out[f"{mode}_{k}"] = np.float64(loss[k].item())
+        if mode == "train":
+            loss["loss"].backward()
+            for k, p in m2.named_parameters():
+                out["grad::" + k] = p.grad.detach().numpy()
+            out.update({"after_fwd_" + k: v for k, v in np_state(m2.state_dict()).items() if "running" in k or "tracked" in k})
+        if lik == "dict-gauss" and mode == "eval":
+            out["eval_cov"] = m2.decoder.create_covariance_matrix(xd["params"]).detach().numpy()
+            torch.manual_seed(seed + 7)
+            e2 = torch.randn((2, *xd["params"]["sigma"].shape))
+            torch.manual_seed(seed + 7)
+            out["eval_dict_rsample_eps"] = e2.numpy()
+            out["eval_dict_rsample"] = m2.decoder.rsample(xd["params"], num_samples=2).detach().numpy()
+
+    # train_core steps (2-D conditions only: that is what training uses)
+    if not three_d:
+        torch.manual_seed(seed)
+        m3 = CVAE(input_dim=D, conditioner=Cdim(C), **cfg)
+        m3.load_state_dict(model.state_dict())
+        m3.train()
+        m3.train_kwargs = {"num_mc_samples": S, "beta": 0.7, "gradient_clipping": True,
+                           "gradient_clipping_kwargs": {"max_norm": 1.0}}
+        optim = m3.get_optimizer(lr=1e-3, weight_decay=1e-5)
+        xs, cs, es, ls = [], [], [], []
+        for t in range(steps):
+            xb = torch.tensor(synth_profiles(B, D, rng))
+            cb = torch.tensor(rng.normal(size=(B, C)).astype(np.float32))
+            torch.manual_seed(seed + 1000 + t)
+            eps = torch.randn((S, B, L))
+            torch.manual_seed(seed + 1000 + t)
+            loss = m3.train_core((xb, cb), optim)
+            xs.append(xb.numpy()); cs.append(cb.numpy()); es.append(eps.numpy())
+            ls.append([loss[k].item() for k in ("loss", "elbo", "rll", "kl")])
+        out["steps_x"], out["steps_c"], out["steps_eps"] = np.stack(xs), np.stack(cs), np.stack(es)
+        out["steps_losses"] = np.array(ls, dtype=np.float64)
+        out.update({"final::" + k: v.detach().numpy() for k, v in m3.state_dict().items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name)
+
+
+def case_config0_shape(name="config0_smallbatch", seed=2112, B=64, S=4, steps=3):
+    """config0 architecture (H=1000, D=48, L=48, V=100) at a small batch; weights are not stored
+    (41 MB): the fixture pins seed-reproducible construction plus the per-step loss terms and a few
+    parameter slices after the last step."""
+    cfg = json.load(open(os.path.join(REF, "config_files", "config0.json")))
+    mcfg = cfg["model"]
+    D, C, L = 48, 4, mcfg["latent_dim"]
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    model = CVAE(input_dim=D, conditioner=Cdim(C), **mcfg)
+    model.train()
+    model.train_kwargs = {"num_mc_samples": S, "beta": cfg["train"]["beta"], "gradient_clipping": True,
+                          "gradient_clipping_kwargs": cfg["train"]["gradient_clipping_kwargs"]}
+    out = {"model_cfg": json.dumps(mcfg), "seed": seed, "D": D, "C": C, "B": B, "S": S,
+           "lr": cfg["train"]["lr"], "weight_decay": cfg["train"]["weight_decay"], "beta": cfg["train"]["beta"]}
+    sd0 = model.state_dict()
+    for k in ("encoder.parameterizer.block_dict.input.input_layer.0.weight",
+              "decoder.parameterizer.block_dict.sigma.output_layer.0.bias", "decoder.SigmaMapper"):
+        out["init::" + k] = sd0[k].detach().numpy().reshape(-1)[:64].copy()
+    optim = model.get_optimizer(lr=cfg["train"]["lr"], weight_decay=cfg["train"]["weight_decay"])
+    xs, cs, es, ls = [], [], [], []
+    for t in range(steps):
+        xb = torch.tensor(synth_profiles(B, D, rng))
+        ang = rng.uniform(0, 2 * np.pi, size=(B, 2))
+        cb = torch.tensor(np.concatenate([np.cos(ang), np.sin(ang)], 1).astype(np.float32))
+        torch.manual_seed(seed + 1000 + t)
+        eps = torch.randn((S, B, L))
+        torch.manual_seed(seed + 1000 + t)
+        loss = model.train_core((xb, cb), optim)
+        xs.append(xb.numpy()); cs.append(cb.numpy()); es.append(eps.numpy())
+        ls.append([loss[k].item() for k in ("loss", "elbo", "rll", "kl")])
+    out["steps_x"], out["steps_c"], out["steps_eps"] = np.stack(xs), np.stack(cs), np.stack(es)
+    out["steps_losses"] = np.array(ls, dtype=np.float64)
+    sd1 = model.state_dict()
+    for k in ("encoder.parameterizer.block_dict.input.input_layer.0.weight",
+              "decoder.parameterizer.block_dict.input.middle_layers.1.0.weight",
+              "decoder.parameterizer.block_dict.sigma.output_layer.0.bias",
+              "decoder.parameterizer.block_dict.mu.input_layer.2.running_var", "decoder.SigmaMapper"):
+        out["final::" + k] = sd1[k].detach().numpy().reshape(-1)[:64].copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, ls)
+
+
+class DrawLog:
+    """Records every torch.randn / torch.randn_like result while active."""
+    def __init__(self):
+        self.randn, self.randn_like = [], []
+
+    def __enter__(self):
+        self._r, self._rl = torch.randn, torch.randn_like
+        def randn(*a, **k):
+            t = self._r(*a, **k); self.randn.append(t.clone()); return t
+        def randn_like(*a, **k):
+            t = self._rl(*a, **k); self.randn_like.append(t.clone()); return t
+        torch.randn, torch.randn_like = randn, randn_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.randn_like = self._r, self._rl
+
+
+def case_scoring(name="scoring_tiny", seed=5, N=20, K=7, D=6):
+    rng = np.random.default_rng(seed)
+    cfg = tiny_model_cfg("dict-gauss")
+    cond, cset = make_conditioner(N, rng)
+    torch.manual_seed(seed)
+    model = CVAE(input_dim=D, conditioner=cond, **cfg)
+    # make BN running stats non-trivial, then eval
+    model.train()
+    with torch.no_grad():
+        for _ in range(3):
+            model.forward(torch.tensor(synth_profiles(16, D, rng)), torch.tensor(rng.normal(size=(16, 4)).astype(np.float32)), num_mc_samples=2)
+    model.eval()
+    X = synth_profiles(N, D, rng)
+    with DrawLog() as log:
+        ll, rlls, kl = testing_lib.mass_loglikelihood(model, X, cond, cset, num_mc_samples=K, batch_size=8, mc_sample_batch_size=3, device="cpu")
+    # first randn call is the shape probe (src/testing_lib.py:27); the rest are [chunk, batch, L] draws in (batch, chunk) order
+    draws = log.randn[1:]
+    L = cfg["latent_dim"]
+    eps = np.zeros((K, N, L), np.float32)
+    bi = 0
+    it = iter(draws)
+    for k0 in range(0, N, 8):
+        for i0 in range(0, K, 3):
+            d = next(it).numpy()
+            eps[i0:i0 + d.shape[0], k0:k0 + d.shape[1]] = d
+    out = {"model_cfg": json.dumps(cfg), "D": D, "N": N, "K": K, "x": X,
+           "c": cond.transform(cset).astype(np.float32), "months": cset["months"], "weekdays": cset["weekdays"],
+           "eps": eps, "ll": ll, "rlls": rlls, "kl": kl}
+    out.update(np_state(model.state_dict()))
+    # prior-sample scoring (src/vae_models.py:283-290 + decoder.log_likelihood)
+    ctens = torch.tensor(cond.transform(cset)).float()
+    with DrawLog() as log2:
+        sdict = model.sample(ctens, num_samples_prior=4, num_samples_likelihood=1)
+    z = log2.randn[0].reshape(4, N, L)
+    out["prior_z"] = z.numpy()
+    out["prior_rll"] = model.decoder.log_likelihood(torch.tensor(X), sdict["params"]).detach().numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name)
+
+
+def case_imputation(name="imputation_tiny", seed=9, N=10, D=6, W=3, T=5, num_samples=3):
+    rng = np.random.default_rng(seed)
+    cfg = tiny_model_cfg("dict-gauss")
+    cond, cset = make_conditioner(N, rng)
+    torch.manual_seed(seed)
+    model = CVAE(input_dim=D, conditioner=cond, **cfg)
+    model.train()
+    with torch.no_grad():
+        for _ in range(3):
+            model.forward(torch.tensor(synth_profiles(16, D, rng)), torch.tensor(rng.normal(size=(16, 4)).astype(np.float32)), num_mc_samples=2)
+    model.eval()
+    X = synth_profiles(N, D, rng)
+    x_missing = X.copy()
+    x_missing[:, -W:] = np.nan
+    target = X[:, -W:]
+    with DrawLog() as log:
+        ll, samples = imputation_lib.mass_cvae_imputation_with_loglikelihood(
+            model, x_missing, target, cond, cset, batch_size=6, num_samples=num_samples, num_iter=0,
+            warmup_steps=T, verbose_freq=1000, device="cpu")
+    # per batch: 1 slack randn + 1 slack randn_like (src/imputation_lib.py:66,70), then T (randn, randn_like) pairs
+    L = cfg["latent_dim"]
+    eps_z = np.zeros((T, N, L), np.float32)
+    eps_x = np.zeros((T, N, W), np.float32)
+    r, rl = iter(log.randn), iter(log.randn_like)
+    for b0 in range(0, N, 6):
+        next(r); next(rl)
+        for t in range(T):
+            dz = next(r).numpy(); dx = next(rl).numpy()
+            eps_z[t, b0:b0 + dz.shape[1]] = dz[0]
+            eps_x[t, b0:b0 + dx.shape[0]] = dx
+    # single-batch call for the ring buffers themselves
+    torch.manual_seed(seed + 1)
+    with DrawLog() as log2:
+        cs, cm, cc, x_rec, z_rec = imputation_lib.cvae_imputation(model, x_missing, cond, cset, num_samples=num_samples,
+                                                                  num_iter=0, warmup_steps=T, device="cpu")
+    ez2 = np.stack([t.numpy()[0] for t in log2.randn[1:]])
+    ex2 = np.stack([t.numpy() for t in log2.randn_like[1:]])
+    out = {"model_cfg": json.dumps(cfg), "D": D, "N": N, "W": W, "T": T, "num_samples": num_samples,
+           "x_missing": x_missing, "target": target, "c": cond.transform(cset).astype(np.float32),
+           "eps_z": eps_z, "eps_x": eps_x, "batch_size": 6, "loglik": ll, "samples": samples,
+           "one_eps_z": ez2, "one_eps_x": ex2, "one_cond_samples": cs.numpy(), "one_cond_mean": cm.numpy(),
+           "one_cond_cov": cc.numpy()}
+    out.update(np_state(model.state_dict()))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name)
+
+
+def case_pointwise(name="pointwise"):
+    xs = torch.tensor([-30.0, -10.0, -1.0, 0.0, 1.0, 4.9, 5.0, 5.0001, 5.1, 10.0, 40.0])
+    out = {"softplus_in": xs.numpy(), "softplus_out": ref_utils.to_sigma(xs).numpy()}
+    mu = torch.tensor([[0.3, -1.2, 2.0]]); sg = torch.tensor([[0.5, 1.0, 0.05]]); t = torch.tensor([[0.0, 1.0, 2.1]])
+    out["lp_mu"], out["lp_sigma"], out["lp_t"] = mu.numpy(), sg.numpy(), t.numpy()
+    out["lp_out"] = ref_utils.log_prob("Normal", {"mu": mu, "sigma": sg}, t).numpy()
+    out["kl_out"] = ref_utils.kl_divergence("Normal", {"mu": mu, "sigma": sg}, {"mu": torch.zeros(3), "sigma": torch.ones(3)}).numpy()
+    U = torch.tensor(np.random.default_rng(3).normal(size=(4, 6)).astype(np.float32))
+    out["U"], out["U_norm"] = U.numpy(), ref_utils.matrix_normalizer(U).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name)
+
+
+def case_conditioner(name="conditioner"):
+    rng = np.random.default_rng(11)
+    n, T = 12, 5
+    months = rng.integers(1, 13, size=(n, 1)); weekdays = rng.integers(0, 7, size=(n, 1))
+    day_before = rng.normal(size=(n, 3)); gammas = rng.gamma(2.0, 1.0, size=(n, T)) + 0.01
+    out = {"months": months, "weekdays": weekdays, "day_befores": day_before, "users": gammas}
+    for style in ("mean", "embed", "scaled", "sample"):
+        cset = {"months": months, "weekdays": weekdays, "day_befores": day_before, "users": gammas}
+        cond = Conditioner(tags=["months", "weekdays", "day_befores", "users"],
+                           supports=[list(range(1, 13)), list(range(7)), [-3, 3], [0.01, 10.0]],
+                           types=["circ", "circ", "identity", "dir"], condition_set=cset)
+        cond.transformers["users"].transform_style = style
+        np.random.seed(4)
+        res = cond.transform(cset, num_samples=3)
+        out["out_" + style] = res
+        out["cond_dim"] = cond.cond_dim
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    case_pointwise()
+    case_conditioner()
+    case_forward_train("tiny_dict_2d", "dict-gauss", seed=1)
+    case_forward_train("tiny_dict_3d", "dict-gauss", seed=2, three_d=True)
+    case_forward_train("tiny_normal_2d", "normal", seed=3)
+    case_scoring()
+    case_imputation()
+    case_config0_shape()

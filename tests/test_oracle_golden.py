@@ -1,0 +1,128 @@
+"""CPU: the oracle restatement against every golden vector produced by the reference
+(tests/golden/*.npz, generator oracle/make_golden.py).  Tolerances are fp32 round-off of two
+differently ordered but mathematically identical CPU computations."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_spec, golden_state, load_golden, rel_err
+from oracle import refimpl as R
+
+T = lambda a: torch.from_numpy(np.array(a))
+
+
+def test_pointwise():
+    g = load_golden("pointwise")
+    assert np.allclose(R.softplus_thr(T(g["softplus_in"])).numpy(), g["softplus_out"], rtol=1e-6, atol=1e-7)
+    lp = R.normal_log_prob(T(g["lp_t"]), T(g["lp_mu"]), T(g["lp_sigma"]))
+    assert np.allclose(lp.numpy(), g["lp_out"], rtol=1e-6, atol=1e-6)
+    kl = R.normal_kl(T(g["lp_mu"]), T(g["lp_sigma"]), 0.0, 1.0)
+    assert np.allclose(kl.numpy(), g["kl_out"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(R.sigma_mapper(T(g["U"])).numpy(), g["U_norm"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["tiny_dict_2d", "tiny_dict_3d", "tiny_normal_2d"])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_forward_and_loss(name, mode):
+    g = load_golden(name)
+    spec, _ = golden_spec(g)
+    sd = golden_state(g)
+    x, c, eps = T(g["x"]), T(g["c"]), T(g[f"{mode}_eps"])
+    upd = {}
+    lik, post, z = R.cvae_forward(sd, spec, x, c, eps, mode == "train", upd)
+    assert np.allclose(post["mu"].numpy(), g[f"{mode}_post_mu"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(post["sigma"].numpy(), g[f"{mode}_post_sigma"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(z.numpy(), g[f"{mode}_z"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(lik["mu"].numpy(), g[f"{mode}_lik_mu"], rtol=1e-4, atol=2e-5)
+    assert np.allclose(lik["sigma"].numpy(), g[f"{mode}_lik_sigma"], rtol=1e-4, atol=2e-5)
+    rows = R.decoder_log_likelihood(sd, spec.dec, x, lik)
+    assert rel_err(rows.numpy(), g[f"{mode}_rll_rows"]) < 1e-4
+    terms = R.elbo_terms(sd, spec, x, lik, post, beta=0.7)
+    for k in ("loss", "elbo", "rll", "kl"):
+        assert abs(float(terms[k]) - float(g[f"{mode}_{k}"])) <= 1e-4 * abs(float(g[f"{mode}_{k}"])) + 1e-5
+    if mode == "train":
+        for k, v in upd.items():
+            assert np.allclose(v.numpy(), g["after_fwd_sd::" + k], rtol=1e-5, atol=1e-6), k
+    if mode == "eval" and name.startswith("tiny_dict"):
+        cov = R.dict_covariance(sd["decoder.SigmaMapper"], lik["sigma"], spec.dec.marginal_std_lim)
+        assert np.allclose(cov.numpy(), g["eval_cov"], rtol=1e-4, atol=1e-6)
+        rs = R.dict_rsample(sd["decoder.SigmaMapper"], lik["mu"], lik["sigma"], T(g["eval_dict_rsample_eps"]))
+        assert np.allclose(rs.numpy(), g["eval_dict_rsample"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["tiny_dict_2d", "tiny_normal_2d"])
+def test_gradients(name):
+    g = load_golden(name)
+    spec, _ = golden_spec(g)
+    sd = golden_state(g)
+    keys = R.parameter_keys(spec)
+    assert sorted(keys) == sorted(k[len("grad::"):] for k in g if k.startswith("grad::"))
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
+    work = dict(sd); work.update(leaves)
+    lik, post, _ = R.cvae_forward(work, spec, T(g["x"]), T(g["c"]), T(g["train_eps"]), True, {})
+    loss = R.elbo_terms(work, spec, T(g["x"]), lik, post, beta=0.7)["loss"]
+    grads = torch.autograd.grad(loss, [leaves[k] for k in keys])
+    for k, gr in zip(keys, grads):
+        ref = g["grad::" + k]
+        scale = np.abs(ref).max() + 1e-8
+        assert np.abs(gr.numpy() - ref).max() <= 2e-4 * scale + 1e-6, k
+
+
+@pytest.mark.parametrize("name", ["tiny_dict_2d", "tiny_normal_2d"])
+def test_train_steps(name):
+    g = load_golden(name)
+    spec, _ = golden_spec(g)
+    sd = golden_state(g)
+    st = R.AdamState()
+    for t in range(g["steps_x"].shape[0]):
+        terms, _, _ = R.train_step(sd, spec, st, T(g["steps_x"][t]), T(g["steps_c"][t]), T(g["steps_eps"][t]),
+                                   lr=1e-3, weight_decay=1e-5, beta=0.7, max_norm=1.0)
+        got = [terms[k] for k in ("loss", "elbo", "rll", "kl")]
+        assert rel_err(got, g["steps_losses"][t]) < 1e-4, (t, got, g["steps_losses"][t])
+    for k, v in sd.items():
+        ref = g["final::" + k]
+        if v.is_floating_point():
+            assert np.abs(v.numpy() - ref).max() <= 2e-4 * (np.abs(ref).max() + 1e-6), k
+        else:
+            assert int(v) == int(ref), k
+
+
+def test_scoring():
+    g = load_golden("scoring_tiny")
+    spec, _ = golden_spec(g)
+    sd = golden_state(g)
+    ll, rlls, kl = R.iw_loglikelihood(sd, spec, T(g["x"]), T(g["c"]), T(g["eps"]))
+    assert rel_err(rlls.numpy(), g["rlls"]) < 1e-4
+    assert rel_err(ll.numpy(), g["ll"]) < 1e-4
+    assert rel_err(kl.numpy(), g["kl"]) < 1e-4
+    pr = R.prior_sample_loglik(sd, spec, T(g["x"]), T(g["c"]), T(g["prior_z"]))
+    assert rel_err(pr.numpy(), g["prior_rll"]) < 1e-4
+
+
+def test_imputation():
+    g = load_golden("imputation_tiny")
+    spec, _ = golden_spec(g)
+    sd = golden_state(g)
+    xm = T(g["x_missing"]).float()
+    mask = torch.isnan(xm)
+    # bit-exact mask / index handling
+    assert mask[:, -int(g["W"]):].all() and not mask[:, :-int(g["W"])].any()
+    x0 = xm.clone()
+    x0[mask] = x0[~mask].mean()
+    c = T(g["c"])
+    ns = int(g["num_samples"])
+    cs, cm, cc, _ = R.pseudo_gibbs(sd, spec, x0, mask, c, T(g["one_eps_z"]), T(g["one_eps_x"]), ns)
+    assert np.allclose(cm.numpy(), g["one_cond_mean"], rtol=2e-4, atol=2e-5)
+    assert np.allclose(cc.numpy(), g["one_cond_cov"], rtol=2e-4, atol=2e-6)
+    assert np.allclose(cs.numpy(), g["one_cond_samples"], rtol=2e-4, atol=2e-5)
+    # batched driver with log-likelihood: per-batch init mean and ring buffers
+    bs, N = int(g["batch_size"]), int(g["N"])
+    lls = []
+    for b0 in range(0, N, bs):
+        xb = xm[b0:b0 + bs].clone(); mb = torch.isnan(xb)
+        xb[mb] = xb[~mb].mean()
+        cs, cm, cc, _ = R.pseudo_gibbs(sd, spec, xb, mb, c[b0:b0 + bs], T(g["eps_z"])[:, b0:b0 + bs],
+                                       T(g["eps_x"])[:, b0:b0 + bs], ns)
+        lls.append(R.mixture_loglik(cm, cc, T(g["target"])[b0:b0 + bs]))
+        assert np.allclose(cs.numpy(), g["samples"][:, b0:b0 + bs], rtol=2e-4, atol=2e-5)
+    assert rel_err(torch.cat(lls).numpy(), g["loglik"]) < 2e-4
