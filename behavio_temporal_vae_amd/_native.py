@@ -1,0 +1,140 @@
+"""ctypes binding of ``libbtvae_hip.so`` (the C-ABI declared in ``include/btvae_hip.h``).
+
+There is no CPU fallback: if the shared library is missing or a call fails, a ``RuntimeError`` is
+raised.  torch is used only to own device memory and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_longlong, c_ulonglong, c_void_p
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbtvae_hip.so")
+_lib = None
+_inited = set()
+
+P, I, F, LL, ULL = c_void_p, c_int, c_float, c_longlong, c_ulonglong
+
+# name -> argument types (every function returns int status unless listed in _RET)
+_SIGS = {
+    "btvae_init": [I],
+    "btvae_prof_enable": [I],
+    "btvae_prof_collect": [P, P, P, P, I],
+    "btvae_linear_relu_stats_fwd": [P, I, P, P, P, P, I, I, I, P],
+    "btvae_linear_relu_affine_fwd": [P, I, P, P, P, P, P, P, I, I, I, P],
+    "btvae_linear_head_fwd": [P, I, P, P, I, F, F, P, P, P, I, I, I, P],
+    "btvae_linear_dgrad": [P, P, P, P, I, I, I, I, P],
+    "btvae_linear_wgrad": [P, P, I, P, P, LL, I, I, I, I, P],
+    "btvae_matmul_tn": [P, I, P, I, P, P, LL, I, I, I, I, I, P],
+    "btvae_matmul_nt_bias": [P, I, P, I, P, P, I, I, I, I, P],
+    "btvae_matmul_nn_mul": [P, I, P, I, P, P, I, P, I, I, I, I, P],
+    "btvae_bn_stats_finalize": [P, I, I, I, P, P, P, P, F, F, P],
+    "btvae_bn_fold_eval": [P, P, P, P, F, P, P, I, P],
+    "btvae_bn_apply_fwd": [P, P, P, P, P, P, P, I, I, P],
+    "btvae_bn_relu_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "btvae_colsum": [P, P, P, I, I, I, P],
+    "btvae_reparam_kl_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, ULL, ULL, P],
+    "btvae_reparam_kl_bwd": [P, P, P, P, P, P, P, P, I, I, I, I, F, P],
+    "btvae_diag_gauss_loglik": [P, P, P, P, P, P, P, P, P, F, I, I, I, P],
+    "btvae_dict_prepare": [P, P, P, P, P, I, I, F, P],
+    "btvae_dict_grad": [P, P, P, P, I, I, I, P],
+    "btvae_mvn_rows_fwd": [P, P, P, P, I, I, I, P],
+    "btvae_mvn_rows_fwd_bwd": [P, P, P, P, P, F, P, P, P, I, I, I, P],
+    "btvae_elbo_scalars": [P, I, P, I, F, P, P],
+    "btvae_iw_lse_update": [P, P, P, P, P, P, I, I, I, I, P],
+    "btvae_iw_lse_finalize": [P, P, P, I, I, P],
+    "btvae_grad_sumsq": [P, LL, P, P],
+    "btvae_clip_adam_step": [P, P, P, P, LL, P, F, F, F, F, F, F, LL, P, P],
+    "btvae_scale": [P, LL, F, P],
+    "btvae_cond_mvn_sample": [P, P, P, P, ULL, P, P, P, P, I, I, I, P],
+    "btvae_masked_scatter": [P, P, P, LL, P],
+    "btvae_lse_over_k": [P, P, I, I, P],
+    "btvae_pack_lower": [P, P, LL, I, P],
+}
+_RET = {
+    "btvae_last_error": (ctypes.c_char_p, []),
+    "btvae_version": (c_int, []),
+    "btvae_strip_chunks": (c_int, [I]),
+    "btvae_bn_relu_bwd_scratch": (c_longlong, [I, I]),
+}
+EXPORTS = sorted(list(_SIGS) + list(_RET))
+PROF_KINDS = ["gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_mvn", "bn", "mvn_rows", "reduce", "optim"]
+
+
+def lib():
+    """The loaded shared library; raises if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"HIP extension not built: {_LIB_PATH} is missing (run __graft_entry__.build())")
+        L = ctypes.CDLL(_LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = c_int
+        for name, (ret, args) in _RET.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = ret
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return lib().btvae_last_error().decode("utf-8", "replace")
+
+
+def ensure_device(device: torch.device):
+    """Bind the library to ``device`` (checks that it is a gfx950 part) once per device index."""
+    if device.type != "cuda":
+        raise RuntimeError(f"behavio_temporal_vae_amd computes on MI355X only; got tensors on '{device}'")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _inited:
+        rc = lib().btvae_init(idx)
+        if rc != 0:
+            raise RuntimeError(last_error())
+        _inited.add(idx)
+    return idx
+
+
+def ptr(t):
+    """Device pointer of a contiguous float32/int tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise RuntimeError("non-contiguous tensor passed to the HIP library")
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name: str, *args):
+    """Call a status-returning entry point on the current torch stream; raise on failure."""
+    rc = getattr(lib(), name)(*args, stream_ptr())
+    if rc != 0:
+        raise RuntimeError(f"{name}: {last_error()}")
+
+
+def f32(t, name="tensor"):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def prof_enable(on: bool):
+    lib().btvae_prof_enable(1 if on else 0)
+
+
+def prof_collect():
+    """{family: (ms, flops, bytes, launches)} since ``prof_enable(True)``; call after a device sync."""
+    n = len(PROF_KINDS)
+    ms, fl, by = (c_double * n)(), (c_double * n)(), (c_double * n)()
+    cnt = (c_longlong * n)()
+    rc = lib().btvae_prof_collect(ms, fl, by, cnt, n)
+    if rc != 0:
+        raise RuntimeError(last_error())
+    return {k: (ms[i], fl[i], by[i], cnt[i]) for i, k in enumerate(PROF_KINDS)}

@@ -1,0 +1,309 @@
+// BatchNorm1d (train-mode statistics, apply, backward) and column reductions for [M,N] row-major
+// activations.  All kernels are HBM-bound streaming passes: 16 B per lane, a wave reads 1 KiB of one
+// row per instruction, column sums stay in registers and are merged across the 4 waves through LDS.
+// Cross-workgroup reductions go through small partial arrays finished in fp64 by one thread per
+// column, so results are deterministic (no float atomics).
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int STRIP_COLS = 256;   // columns per workgroup: 64 lanes x float4
+
+// ---- train-mode statistics: merge the per-row-tile (mean, M2) partials of the GEMM epilogue ----
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ partials, int ntiles, int tile_rows, int M, int N,
+                                         float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                         float momentum, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int t = 0; t < ntiles; ++t) {
+        const double nb = (double)min(tile_rows, M - t * tile_rows);
+        const double mb = partials[((size_t)t * 2 + 0) * N + c];
+        const double qb = partials[((size_t)t * 2 + 1) * N + c];
+        const double tot = n + nb, d = mb - mean;
+        m2 += qb + d * d * (n * nb / tot);
+        mean += d * (nb / tot);
+        n = tot;
+    }
+    const double var_b = m2 / n;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = (float)(1.0 / sqrt(var_b + (double)eps));
+    if (running_mean) {
+        const double var_u = n > 1.0 ? m2 / (n - 1.0) : var_b;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var_u);
+    }
+}
+
+__global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                    float* scale, float* shift, int N) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const float s = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = s;
+    shift[c] = beta[c] - rm[c] * s;
+}
+
+// ---- forward apply: Out = (Y - mean) * invstd * gamma + beta (+ R) ----
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ Y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ R,
+                                                           float* __restrict__ Out, int M, int N, int rows_per_chunk) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * VEC;
+    if (col >= N) return;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const float s = invstd[col + j] * gamma[col + j];
+        sc[j] = s; sh[j] = beta[col + j] - mean[col + j] * s;
+    }
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+#pragma unroll 4
+    for (int r = r0 + w; r < r1; r += 4) {
+        const size_t o = (size_t)r * N + col;
+        if (VEC == 4) {
+            float4 y = *reinterpret_cast<const float4*>(Y + o);
+            float4 v = make_float4(y.x * sc[0] + sh[0], y.y * sc[1] + sh[1], y.z * sc[2] + sh[2], y.w * sc[3] + sh[3]);
+            if (R) { const float4 q = *reinterpret_cast<const float4*>(R + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            *reinterpret_cast<float4*>(Out + o) = v;
+        } else {
+            float v = Y[o] * sc[0] + sh[0];
+            if (R) v += R[o];
+            Out[o] = v;
+        }
+    }
+}
+
+// ---- backward pass 1: per column s1 = sum g, s2 = sum g * xhat ----
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ G, const float* __restrict__ Y,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            float* __restrict__ partials, int M, int N, int rows_per_chunk) {
+    __shared__ float red[4][64][2 * VEC];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * VEC;
+    const bool ok = col < N;
+    float mu[VEC], is[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { mu[j] = ok ? mean[col + j] : 0.f; is[j] = ok ? invstd[col + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    if (ok) {
+#pragma unroll 4
+        for (int r = r0 + w; r < r1; r += 4) {
+            const size_t o = (size_t)r * N + col;
+            if (VEC == 4) {
+                const float4 g = *reinterpret_cast<const float4*>(G + o);
+                const float4 y = *reinterpret_cast<const float4*>(Y + o);
+                s1[0] += g.x; s2[0] += g.x * ((y.x - mu[0]) * is[0]);
+                s1[1] += g.y; s2[1] += g.y * ((y.y - mu[1]) * is[1]);
+                s1[2] += g.z; s2[2] += g.z * ((y.z - mu[2]) * is[2]);
+                s1[3] += g.w; s2[3] += g.w * ((y.w - mu[3]) * is[3]);
+            } else {
+                const float g = G[o], y = Y[o];
+                s1[0] += g; s2[0] += g * ((y - mu[0]) * is[0]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[w][lane][j] = s1[j]; red[w][lane][VEC + j] = s2[j]; }
+    __syncthreads();
+    if (w == 0 && ok) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float a = red[0][lane][j] + red[1][lane][j] + red[2][lane][j] + red[3][lane][j];
+            const float b = red[0][lane][VEC + j] + red[1][lane][VEC + j] + red[2][lane][VEC + j] + red[3][lane][VEC + j];
+            partials[((size_t)blockIdx.y * 2 + 0) * N + col + j] = a;
+            partials[((size_t)blockIdx.y * 2 + 1) * N + col + j] = b;
+        }
+    }
+}
+
+// merge [nchunks][nvec][N] partial column sums in fp64; out_k (+)= sum
+__global__ void colsum_finalize_kernel(const float* __restrict__ partials, int nchunks, int nvec, int N,
+                                       float* out0, float* out1, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    for (int k = 0; k < nvec; ++k) {
+        double s = 0.0;
+        for (int t = 0; t < nchunks; ++t) s += partials[((size_t)t * nvec + k) * N + c];
+        float* o = k == 0 ? out0 : out1;
+        if (o) o[c] = accumulate ? o[c] + (float)s : (float)s;
+    }
+}
+
+// ---- backward pass 2: dPre = (y>0) * gamma*invstd * (g - dbeta/M - xhat*dgamma/M); column sums of dPre ----
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ Y,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, float* __restrict__ dPre,
+                                                           float* __restrict__ db_partials, int M, int N, int rows_per_chunk) {
+    __shared__ float red[4][64][VEC];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * VEC;
+    const bool ok = col < N;
+    float mu[VEC], is[VEC], k0[VEC], k1[VEC], k2[VEC], sb[VEC];
+    const float invM = 1.f / (float)M;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        mu[j] = ok ? mean[col + j] : 0.f;
+        is[j] = ok ? invstd[col + j] : 0.f;
+        const float gi = ok ? gamma[col + j] * is[j] : 0.f;
+        k0[j] = gi;                                          // multiplies g
+        k1[j] = ok ? gi * dbeta[col + j] * invM : 0.f;       // constant term
+        k2[j] = ok ? gi * dgamma[col + j] * invM : 0.f;      // multiplies xhat
+        sb[j] = 0.f;
+    }
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    if (ok) {
+#pragma unroll 4
+        for (int r = r0 + w; r < r1; r += 4) {
+            const size_t o = (size_t)r * N + col;
+            if (VEC == 4) {
+                const float4 g = *reinterpret_cast<const float4*>(G + o);
+                const float4 y = *reinterpret_cast<const float4*>(Y + o);
+                float4 d;
+                d.x = y.x > 0.f ? k0[0] * g.x - k1[0] - k2[0] * ((y.x - mu[0]) * is[0]) : 0.f;
+                d.y = y.y > 0.f ? k0[1] * g.y - k1[1] - k2[1] * ((y.y - mu[1]) * is[1]) : 0.f;
+                d.z = y.z > 0.f ? k0[2] * g.z - k1[2] - k2[2] * ((y.z - mu[2]) * is[2]) : 0.f;
+                d.w = y.w > 0.f ? k0[3] * g.w - k1[3] - k2[3] * ((y.w - mu[3]) * is[3]) : 0.f;
+                *reinterpret_cast<float4*>(dPre + o) = d;
+                sb[0] += d.x; sb[1] += d.y; sb[2] += d.z; sb[3] += d.w;
+            } else {
+                const float g = G[o], y = Y[o];
+                const float d = y > 0.f ? k0[0] * g - k1[0] - k2[0] * ((y - mu[0]) * is[0]) : 0.f;
+                dPre[o] = d;
+                sb[0] += d;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[w][lane][j] = sb[j];
+    __syncthreads();
+    if (w == 0 && ok) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            db_partials[(size_t)blockIdx.y * N + col + j] = red[0][lane][j] + red[1][lane][j] + red[2][lane][j] + red[3][lane][j];
+    }
+}
+
+// column sums of a plain [M,N] matrix (bias gradient of layers without ReLU/BN)
+template <int VEC>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ G, float* __restrict__ partials, int M, int N, int rows_per_chunk) {
+    __shared__ float red[4][64][VEC];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * VEC;
+    const bool ok = col < N;
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    if (ok) {
+        for (int r = r0 + w; r < r1; r += 4) {
+            const size_t o = (size_t)r * N + col;
+            if (VEC == 4) { const float4 g = *reinterpret_cast<const float4*>(G + o); s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w; }
+            else s[0] += G[o];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[w][lane][j] = s[j];
+    __syncthreads();
+    if (w == 0 && ok) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            partials[(size_t)blockIdx.y * N + col + j] = red[0][lane][j] + red[1][lane][j] + red[2][lane][j] + red[3][lane][j];
+    }
+}
+
+inline bool vec4_ok(int N, const void* a, const void* b, const void* c, const void* d) {
+    auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return N % 4 == 0 && al(a) && al(b) && al(c) && al(d);
+}
+
+inline int chunk_count(int M) { return std::max(1, std::min(256, (M + 63) / 64)); }
+
+}  // namespace
+
+using namespace btvae;
+
+// Number of row chunks the strip kernels use for M rows (size of their partial arrays).
+BTVAE_API int btvae_strip_chunks(int M) { return chunk_count(M); }
+
+BTVAE_API int btvae_bn_stats_finalize(const float* partials, int ntiles, int M, int N, float* mean, float* invstd,
+                                      float* running_mean, float* running_var, float momentum, float eps, void* stream) {
+    BTVAE_REQUIRE(partials && mean && invstd, "bn_stats_finalize: null pointer");
+    BTVAE_REQUIRE(ntiles == (M + 127) / 128, "bn_stats_finalize: ntiles %d does not match M %d", ntiles, M);
+    BTVAE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize: pass both running buffers or neither");
+    ProfScope ps(PK_BN, (hipStream_t)stream, 0, 8.0 * ntiles * N);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, partials, ntiles, 128, M, N,
+                       mean, invstd, running_mean, running_var, momentum, eps);
+    return check_launch("bn_stats_finalize");
+}
+
+BTVAE_API int btvae_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                 float eps, float* scale, float* shift, int N, void* stream) {
+    BTVAE_REQUIRE(gamma && beta && running_mean && running_var && scale && shift, "bn_fold_eval: null pointer");
+    hipLaunchKernelGGL(bn_fold_eval_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, scale, shift, N);
+    return check_launch("bn_fold_eval");
+}
+
+BTVAE_API int btvae_bn_apply_fwd(const float* Y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                 const float* R, float* Out, int M, int N, void* stream) {
+    BTVAE_REQUIRE(Y && mean && invstd && gamma && beta && Out, "bn_apply_fwd: null pointer");
+    const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
+    ProfScope ps(PK_BN, (hipStream_t)stream, 0, 4.0 * M * N * (R ? 3 : 2));
+    if (vec4_ok(N, Y, R, Out, nullptr))
+        hipLaunchKernelGGL((bn_apply_fwd_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, Out, M, N, rpc);
+    else
+        hipLaunchKernelGGL((bn_apply_fwd_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, Out, M, N, rpc);
+    return check_launch("bn_apply_fwd");
+}
+
+// BatchNorm+ReLU backward.  G = dL/d(BN output), Y = post-ReLU pre-BN activations saved by the forward.
+// Writes dgamma, dbeta ((+)= when accumulate), dPre = dL/d(pre-ReLU linear output) and dbias = column sums of dPre.
+// `scratch` needs 3 * btvae_strip_chunks(M) * N floats.
+BTVAE_API int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mean, const float* invstd, const float* gamma,
+                                float* dgamma, float* dbeta, float* dbias, float* dPre, float* scratch, int M, int N,
+                                int accumulate, void* stream) {
+    BTVAE_REQUIRE(G && Y && mean && invstd && gamma && dgamma && dbeta && dbias && dPre && scratch, "bn_relu_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
+    float* p2 = scratch;                          // [chunks][2][N]
+    float* p1 = scratch + (size_t)2 * chunks * N;   // [chunks][N]
+    const bool v4 = vec4_ok(N, G, Y, dPre, nullptr);
+    ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 5);
+    if (v4) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, p2, M, N, rpc);
+    else    hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, p2, M, N, rpc);
+    // k=0 -> sum g (dbeta), k=1 -> sum g*xhat (dgamma); current-batch values go to the tail of the scratch
+    float* cur_dbeta = scratch + (size_t)3 * chunks * N;
+    float* cur_dgamma = cur_dbeta + N;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, s, p2, chunks, 2, N, cur_dbeta, cur_dgamma, 0);
+    if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, dPre, p1, M, N, rpc);
+    else    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, dPre, p1, M, N, rpc);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, s, p1, chunks, 1, N, dbias, (float*)nullptr, accumulate);
+    // publish dgamma / dbeta
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, s, cur_dbeta, 1, 1, N, dbeta, (float*)nullptr, accumulate);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, s, cur_dgamma, 1, 1, N, dgamma, (float*)nullptr, accumulate);
+    return check_launch("bn_relu_bwd");
+}
+
+// Scratch floats btvae_bn_relu_bwd needs for an [M,N] activation.
+BTVAE_API long long btvae_bn_relu_bwd_scratch(int M, int N) { return (long long)3 * chunk_count(M) * N + 2LL * N; }
+
+// out[N] (+)= column sums of G[M,N]; scratch needs btvae_strip_chunks(M) * N floats.
+BTVAE_API int btvae_colsum(const float* G, float* out, float* scratch, int M, int N, int accumulate, void* stream) {
+    BTVAE_REQUIRE(G && out && scratch, "colsum: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
+    ProfScope ps(PK_BN, s, 0, 4.0 * M * N);
+    if (vec4_ok(N, G, nullptr, nullptr, nullptr))
+        hipLaunchKernelGGL((colsum_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, scratch, M, N, rpc);
+    else
+        hipLaunchKernelGGL((colsum_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, scratch, M, N, rpc);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, s, scratch, chunks, 1, N, out, (float*)nullptr, accumulate);
+    return check_launch("colsum");
+}

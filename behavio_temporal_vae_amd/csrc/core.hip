@@ -1,0 +1,95 @@
+// Library state: last-error string, device check, per-kernel-family event timing.
+#include "common.h"
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+#include <mutex>
+
+namespace btvae {
+
+static thread_local char g_err[BTVAE_MAX_ERR] = "";
+char* err_buf() { return g_err; }
+
+int set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, BTVAE_MAX_ERR, fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+struct ProfRec { int kind; hipEvent_t e0, e1; double flops, bytes; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_free;
+static std::mutex g_mu;
+static thread_local int g_open = -1;
+
+static hipEvent_t get_event() {
+    if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+
+void prof_begin(int kind, hipStream_t s, double flops, double bytes) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    ProfRec r{kind, get_event(), get_event(), flops, bytes};
+    hipEventRecord(r.e0, s);
+    g_recs.push_back(r);
+    g_open = (int)g_recs.size() - 1;
+}
+
+void prof_end(int kind, hipStream_t s) {
+    if (!g_prof_on || g_open < 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    hipEventRecord(g_recs[g_open].e1, s);
+    g_open = -1;
+}
+
+}  // namespace btvae
+
+using namespace btvae;
+
+BTVAE_API const char* btvae_last_error(void) { return err_buf(); }
+BTVAE_API int btvae_version(void) { return 100; }
+
+// Select `device` and verify it is a gfx950 part; every other entry point assumes this was called.
+BTVAE_API int btvae_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    BTVAE_REQUIRE(e == hipSuccess && n > 0, "btvae_init: no HIP device (%s)", hipGetErrorString(e));
+    BTVAE_REQUIRE(device >= 0 && device < n, "btvae_init: device %d out of range (%d devices)", device, n);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    BTVAE_REQUIRE(e == hipSuccess, "btvae_init: hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+    BTVAE_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "btvae_init: device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
+    e = hipSetDevice(device);
+    BTVAE_REQUIRE(e == hipSuccess, "btvae_init: hipSetDevice failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// Turn event timing of kernel families on/off; turning it on clears earlier records.
+BTVAE_API int btvae_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& r : g_recs) { g_free.push_back(r.e0); g_free.push_back(r.e1); }
+    g_recs.clear();
+    g_prof_on = on != 0;
+    return 0;
+}
+
+// After a device synchronisation: per family, summed milliseconds, FLOPs, bytes and launch counts
+// (arrays of PK_COUNT = 8 entries each).  Clears the records.
+BTVAE_API int btvae_prof_collect(double* ms, double* flops, double* bytes, long long* count, int n) {
+    BTVAE_REQUIRE(n >= PK_COUNT, "prof_collect: need %d slots", (int)PK_COUNT);
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int i = 0; i < n; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; count[i] = 0; }
+    for (auto& r : g_recs) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
+            ms[r.kind] += t; flops[r.kind] += r.flops; bytes[r.kind] += r.bytes; count[r.kind] += 1;
+        }
+        g_free.push_back(r.e0); g_free.push_back(r.e1);
+    }
+    g_recs.clear();
+    return 0;
+}

@@ -1,0 +1,424 @@
+// Distribution-level kernels of the conditional VAE: reparameterisation + analytic KL, diagonal
+// Gaussian log-likelihood, dictionary-Gaussian (low-rank + diagonal covariance) multivariate normal
+// log-density with its analytic backward, ELBO scalar reduction and the K-sample importance-weighted
+// logsumexp.  Row-wise kernels map ONE 64-lane wavefront to one row and reduce with wave shuffles;
+// cross-row reductions go through small partial arrays finished in fp64 (deterministic).
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr float LOG_2PI = 1.8378770664093453f;
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// ---- Philox4x32-10 counter RNG -> one standard normal per (seed, offset, index) ----
+__device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned long long offset, unsigned long long idx) {
+    unsigned c0 = (unsigned)idx, c1 = (unsigned)(idx >> 32), c2 = (unsigned)offset, c3 = (unsigned)(offset >> 32);
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float u1 = ((float)c0 + 0.5f) * 2.3283064365386963e-10f;   // (0,1)
+    const float u2 = ((float)c1 + 0.5f) * 2.3283064365386963e-10f;
+    return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// reparameterise + KL.  One wave per posterior row r (R rows).  Draw s of row r is row s*R + r of
+// eps / zc.  zc[s*R+r] = [ mu + sigma*eps | cond(r) ], cond offset = (r / cdiv)*cs_hi + (r % cdiv)*cs_lo.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ sigma,
+                                                             const float* __restrict__ eps, float* __restrict__ eps_out,
+                                                             const float* __restrict__ cond, float* __restrict__ zc,
+                                                             float* __restrict__ klrow, int R, int S, int L, int C,
+                                                             int cdiv, int cs_hi, int cs_lo,
+                                                             unsigned long long seed, unsigned long long offset) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int W = L + C;
+    const float* cr = cond + (size_t)(r / cdiv) * cs_hi + (size_t)(r % cdiv) * cs_lo;
+    float kl = 0.f;
+    for (int l = lane; l < L; l += 64) {
+        const float m = mu[(size_t)r * L + l], sg = sigma[(size_t)r * L + l];
+        const float var = sg * sg;
+        kl += 0.5f * (var + m * m - 1.f - logf(var));
+        for (int s = 0; s < S; ++s) {
+            const size_t row = (size_t)s * R + r;
+            float e;
+            if (eps) e = eps[row * L + l];
+            else { e = philox_normal(seed, offset, row * L + l); if (eps_out) eps_out[row * L + l] = e; }
+            zc[row * W + l] = m + sg * e;
+        }
+    }
+    for (int j = lane; j < C; j += 64) {
+        const float cv = cr[j];
+        for (int s = 0; s < S; ++s) zc[((size_t)s * R + r) * W + L + j] = cv;
+    }
+    kl = wave_sum(kl);
+    if (lane == 0) klrow[r] = kl;
+}
+
+// gradient wrt the encoder head RAW outputs: (sum_s dz + kw*mu) * dfac_mu, (sum_s dz*eps + kw*(sigma - 1/sigma)) * dfac_sigma
+__global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(const float* __restrict__ dzc, const float* __restrict__ eps,
+                                                             const float* __restrict__ mu, const float* __restrict__ sigma,
+                                                             const float* __restrict__ dfac_mu, const float* __restrict__ dfac_sigma,
+                                                             float* __restrict__ draw_mu, float* __restrict__ draw_sigma,
+                                                             int R, int S, int L, int C, float kl_weight) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int W = L + C;
+    for (int l = lane; l < L; l += 64) {
+        float am = 0.f, as = 0.f;
+        for (int s = 0; s < S; ++s) {
+            const size_t row = (size_t)s * R + r;
+            const float dz = dzc[row * W + l];
+            am += dz; as += dz * eps[row * L + l];
+        }
+        const size_t o = (size_t)r * L + l;
+        const float m = mu[o], sg = sigma[o];
+        draw_mu[o] = (am + kl_weight * m) * dfac_mu[o];
+        draw_sigma[o] = (as + kl_weight * (sg - 1.f / sg)) * dfac_sigma[o];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// diagonal Gaussian log-likelihood rows: logp[row] = sum_d log N(x[row % B][d]; mu, sigma)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void diag_loglik_kernel(const float* __restrict__ x, const float* __restrict__ mu,
+                                                          const float* __restrict__ sigma, float* __restrict__ logp,
+                                                          const float* __restrict__ dfac_mu, const float* __restrict__ dfac_sigma,
+                                                          float* __restrict__ draw_mu, float* __restrict__ draw_sigma,
+                                                          const float* __restrict__ g_rows, float g_const,
+                                                          int rows, int B, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float g = g_rows ? g_rows[row] : g_const;
+    float acc = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const size_t o = (size_t)row * D + d;
+        const float m = mu[o], sg = sigma[o], t = x[(size_t)(row % B) * D + d];
+        const float u = (t - m) / sg;
+        acc += -0.5f * LOG_2PI - logf(sg) - 0.5f * u * u;
+        if (draw_mu) {
+            draw_mu[o] = g * (u / sg) * dfac_mu[o];
+            draw_sigma[o] = g * ((u * u - 1.f) / sg) * dfac_sigma[o];
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) logp[row] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dictionary tables: Uhat = U / ||U[:,v]||, UU[p][v] = Uhat[d,v]*Uhat[e,v] for packed p = d(d+1)/2+e (e<=d),
+// diag[p] = m^2 on the diagonal entries.  Sigma_packed = sigma^2 @ UU^T + diag.
+// ---------------------------------------------------------------------------------------------
+__global__ void dict_norm_kernel(const float* __restrict__ U, float* __restrict__ Uhat, float* __restrict__ norms, int D, int V) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) { const float u = U[(size_t)d * V + v]; s += u * u; }
+    const float n = sqrtf(s);
+    norms[v] = n;
+    for (int d = 0; d < D; ++d) Uhat[(size_t)d * V + v] = U[(size_t)d * V + v] / n;
+}
+
+__global__ void dict_tables_kernel(const float* __restrict__ Uhat, float* __restrict__ UU, float* __restrict__ diag, int D, int V, float m2) {
+    const int NP = D * (D + 1) / 2;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)NP * V) return;
+    const int p = (int)(i / V), v = (int)(i % V);
+    int d = (int)((sqrtf(8.f * p + 1.f) - 1.f) * 0.5f);
+    while ((d + 1) * (d + 2) / 2 <= p) ++d;
+    while (d * (d + 1) / 2 > p) --d;
+    const int e = p - d * (d + 1) / 2;
+    UU[i] = Uhat[(size_t)d * V + v] * Uhat[(size_t)e * V + v];
+    if (v == 0) diag[p] = d == e ? m2 : 0.f;
+}
+
+// dU (+)= d/dU of the likelihood given M1[p][v] = sum_rows Pg[row][p] * sigma^2[row][v]; one wave per column v.
+__global__ __launch_bounds__(64) void dict_grad_kernel(const float* __restrict__ M1, const float* __restrict__ Uhat,
+                                                       const float* __restrict__ norms, float* __restrict__ dU,
+                                                       int D, int V, int accumulate) {
+    const int v = blockIdx.x, d = threadIdx.x;
+    float g = 0.f, uh = 0.f;
+    if (d < D) {
+        uh = Uhat[(size_t)d * V + v];
+        for (int e = 0; e < D; ++e) {
+            const int mx = max(d, e), mn = min(d, e);
+            const float pv = M1[(size_t)(mx * (mx + 1) / 2 + mn) * V + v] * (d == e ? 1.f : 0.5f);
+            g += pv * Uhat[(size_t)e * V + v];
+        }
+    }
+    const float dot = wave_sum(g * uh);
+    if (d < D) {
+        const float out = (g - uh * dot) / norms[v];
+        const size_t o = (size_t)d * V + v;
+        dU[o] = accumulate ? dU[o] + out : out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MVN rows.  One wave per row; lane i holds row i of the D x D covariance in registers (DP >= D,
+// padded with identity).  BWD: in-place Gauss-Jordan inversion (pivots = LDL^T pivots, so
+// logdet = sum log pivot), alpha = Sigma^-1 (x - mu), P = alpha alpha^T - Sigma^-1.
+// Outputs: logp; dmu_raw = g*alpha*dfac_mu; Pg packed = g * P * (1 on the diagonal, 2 off it).
+// !BWD: forward elimination only (half the work): maha = sum y_k^2 / d_k.
+// ---------------------------------------------------------------------------------------------
+template <int DP, bool BWD>
+__global__ __launch_bounds__(256) void mvn_rows_kernel(const float* __restrict__ Sp, const float* __restrict__ mu,
+                                                       const float* __restrict__ x, const float* __restrict__ dfac_mu,
+                                                       const float* __restrict__ g_rows, float g_const,
+                                                       float* __restrict__ logp, float* __restrict__ dmu_raw,
+                                                       float* __restrict__ Pg, int rows, int B, int D) {
+    constexpr int NPMAX = DP * (DP + 1) / 2;
+    __shared__ float sh[4][NPMAX];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row_raw = blockIdx.x * 4 + w;
+    const bool live = row_raw < rows;
+    const int row = live ? row_raw : rows - 1;
+    const int NP = D * (D + 1) / 2;
+    const int i = lane;
+
+    for (int p = lane; p < NP; p += 64) sh[w][p] = Sp[(size_t)row * NP + p];
+    __syncthreads();
+
+    float a[DP];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+        float v = (i == j) ? 1.f : 0.f;
+        if (i < D && j < D) { const int mx = max(i, j), mn = min(i, j); v = sh[w][mx * (mx + 1) / 2 + mn]; }
+        if (i >= DP) v = 0.f;
+        a[j] = v;
+    }
+    float r = 0.f;
+    if (i < D) r = x[(size_t)(row % B) * D + i] - mu[(size_t)row * D + i];
+
+    float logdet = 0.f, maha = 0.f, alpha = 0.f;
+    if (BWD) {
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+            const float piv = readlane_f(a[k], k);
+            logdet += logf(piv);
+            const float rp = 1.f / piv;
+            const float gk = (i == k) ? (1.f - rp) : a[k] * rp;
+#pragma unroll
+            for (int j = 0; j < DP; ++j) {
+                if (j != k) { const float s = readlane_f(a[j], k); a[j] = fmaf(-gk, s, a[j]); }
+            }
+            a[k] = (i == k) ? rp : -gk;
+        }
+#pragma unroll
+        for (int j = 0; j < DP; ++j) alpha = fmaf(a[j], readlane_f(r, j), alpha);
+        maha = wave_sum(r * alpha);
+    } else {
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+            const float piv = readlane_f(a[k], k);
+            logdet += logf(piv);
+            const float rp = 1.f / piv;
+            const float yk = readlane_f(r, k);
+            maha = fmaf(yk * yk, rp, maha);
+            const float f = (i > k) ? a[k] * rp : 0.f;
+            r = fmaf(-f, yk, r);
+#pragma unroll
+            for (int j = k + 1; j < DP; ++j) { const float s = readlane_f(a[j], k); a[j] = fmaf(-f, s, a[j]); }
+        }
+    }
+    const float lp = -0.5f * ((float)D * LOG_2PI + maha) - 0.5f * logdet;
+    if (live && lane == 0) logp[row] = lp;
+
+    if (BWD) {
+        const float g = g_rows ? g_rows[row] : g_const;
+        if (live && i < D) dmu_raw[(size_t)row * D + i] = g * alpha * dfac_mu[(size_t)row * D + i];
+        __syncthreads();   // every wave has finished gathering from sh
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+            const float aj = readlane_f(alpha, j);
+            if (i < D && j <= i) sh[w][i * (i + 1) / 2 + j] = g * (alpha * aj - a[j]) * (i == j ? 1.f : 2.f);
+        }
+        __syncthreads();
+        if (live) for (int p = lane; p < NP; p += 64) Pg[(size_t)row * NP + p] = sh[w][p];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ELBO scalars: out = [loss, elbo, rll, kl], rll = mean(logp), kl = mean(klrow), loss = -(rll - beta*kl)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void elbo_scalars_kernel(const float* __restrict__ logp, int nlog, const float* __restrict__ klrow,
+                                                            int nkl, float beta, float* __restrict__ out) {
+    __shared__ double red[2][16];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nlog; i += 1024) a += logp[i];
+    for (int i = threadIdx.x; i < nkl; i += 1024) b += klrow[i];
+    a = wave_sum_d(a); b = wave_sum_d(b);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sa = 0.0, sb = 0.0;
+        for (int i = 0; i < 16; ++i) { sa += red[0][i]; sb += red[1][i]; }
+        const float rll = (float)(sa / nlog), kl = (float)(sb / nkl);
+        out[0] = -(rll - beta * kl); out[1] = rll - kl; out[2] = rll; out[3] = kl;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// importance-weighted logsumexp, streamed over chunks of kc samples.  One wave per profile n.
+// w_k = rll[k][n] + sum_l (log sigma_l + eps^2/2 - z^2/2), z = mu + sigma*eps   (= -log q + log p(x|z) + log p(z))
+// running (m, s): log-sum = m + log s.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void iw_lse_update_kernel(const float* __restrict__ rll, const float* __restrict__ eps,
+                                                            const float* __restrict__ mu, const float* __restrict__ sigma,
+                                                            float* __restrict__ m_run, float* __restrict__ s_run,
+                                                            int kc, int N, int L, int first) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float m = first ? -INFINITY : m_run[n];
+    float s = first ? 0.f : s_run[n];
+    for (int k = 0; k < kc; ++k) {
+        float acc = 0.f;
+        for (int l = lane; l < L; l += 64) {
+            const float mm = mu[(size_t)n * L + l], sg = sigma[(size_t)n * L + l];
+            const float e = eps[((size_t)k * N + n) * L + l];
+            const float z = mm + sg * e;
+            acc += logf(sg) + 0.5f * e * e - 0.5f * z * z;
+        }
+        const float wk = wave_sum(acc) + rll[(size_t)k * N + n];
+        const float mn = fmaxf(m, wk);
+        s = s * expf(m - mn) + expf(wk - mn);
+        m = mn;
+    }
+    if (lane == 0) { m_run[n] = m; s_run[n] = s; }
+}
+
+__global__ void iw_lse_finalize_kernel(const float* __restrict__ m_run, const float* __restrict__ s_run, float* __restrict__ ll, int N, float logK) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) ll[n] = m_run[n] + logf(s_run[n]) - logK;
+}
+
+template <bool BWD>
+int launch_mvn(int D, const float* Sp, const float* mu, const float* x, const float* dfac_mu, const float* g_rows, float g_const,
+               float* logp, float* dmu_raw, float* Pg, int rows, int B, hipStream_t s) {
+    dim3 grid((rows + 3) / 4), block(256);
+#define BTVAE_MVN_CASE(DPV) hipLaunchKernelGGL((mvn_rows_kernel<DPV, BWD>), grid, block, 0, s, Sp, mu, x, dfac_mu, g_rows, g_const, logp, dmu_raw, Pg, rows, B, D)
+    if (D <= 8) BTVAE_MVN_CASE(8);
+    else if (D <= 16) BTVAE_MVN_CASE(16);
+    else if (D <= 24) BTVAE_MVN_CASE(24);
+    else if (D <= 32) BTVAE_MVN_CASE(32);
+    else if (D <= 48) BTVAE_MVN_CASE(48);
+    else BTVAE_MVN_CASE(64);
+#undef BTVAE_MVN_CASE
+    return btvae::check_launch("mvn_rows");
+}
+
+}  // namespace
+
+using namespace btvae;
+
+BTVAE_API int btvae_reparam_kl_fwd(const float* mu, const float* sigma, const float* eps, float* eps_out, const float* cond,
+                                   float* zc, float* klrow, int R, int S, int L, int C, int cdiv, int cs_hi, int cs_lo,
+                                   unsigned long long seed, unsigned long long offset, void* stream) {
+    BTVAE_REQUIRE(mu && sigma && zc && klrow && (cond || C == 0), "reparam_kl_fwd: null pointer");
+    BTVAE_REQUIRE(R > 0 && S > 0 && L > 0 && C >= 0 && cdiv > 0, "reparam_kl_fwd: bad shape R=%d S=%d L=%d C=%d", R, S, L, C);
+    ProfScope ps(PK_REDUCE, (hipStream_t)stream, 0, 4.0 * ((double)S * R * (2 * L + C) + 2.0 * R * L));
+    hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, mu, sigma, eps, eps_out, cond, zc, klrow,
+                       R, S, L, C, cdiv, cs_hi, cs_lo, seed, offset);
+    return check_launch("reparam_kl_fwd");
+}
+
+BTVAE_API int btvae_reparam_kl_bwd(const float* dzc, const float* eps, const float* mu, const float* sigma, const float* dfac_mu,
+                                   const float* dfac_sigma, float* draw_mu, float* draw_sigma, int R, int S, int L, int C,
+                                   float kl_weight, void* stream) {
+    BTVAE_REQUIRE(dzc && eps && mu && sigma && dfac_mu && dfac_sigma && draw_mu && draw_sigma, "reparam_kl_bwd: null pointer");
+    ProfScope ps(PK_REDUCE, (hipStream_t)stream, 0, 4.0 * ((double)S * R * (2 * L + C) + 6.0 * R * L));
+    hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, dzc, eps, mu, sigma, dfac_mu, dfac_sigma,
+                       draw_mu, draw_sigma, R, S, L, C, kl_weight);
+    return check_launch("reparam_kl_bwd");
+}
+
+// logp[rows]; when draw_mu/draw_sigma are given also the gradients wrt the raw head outputs, scaled by g.
+BTVAE_API int btvae_diag_gauss_loglik(const float* x, const float* mu, const float* sigma, float* logp, const float* dfac_mu,
+                                      const float* dfac_sigma, float* draw_mu, float* draw_sigma, const float* g_rows, float g_const,
+                                      int rows, int B, int D, void* stream) {
+    BTVAE_REQUIRE(x && mu && sigma && logp, "diag_gauss_loglik: null pointer");
+    BTVAE_REQUIRE((draw_mu == nullptr) == (draw_sigma == nullptr), "diag_gauss_loglik: pass both gradient outputs or neither");
+    BTVAE_REQUIRE(!draw_mu || (dfac_mu && dfac_sigma), "diag_gauss_loglik: gradients need dfac inputs");
+    BTVAE_REQUIRE(rows > 0 && B > 0 && D > 0, "diag_gauss_loglik: bad shape");
+    ProfScope ps(PK_REDUCE, (hipStream_t)stream, 0, 4.0 * rows * D * (draw_mu ? 6 : 2));
+    hipLaunchKernelGGL(diag_loglik_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, mu, sigma, logp, dfac_mu, dfac_sigma,
+                       draw_mu, draw_sigma, g_rows, g_const, rows, B, D);
+    return check_launch("diag_gauss_loglik");
+}
+
+// Uhat[D,V], norms[V], UU[D(D+1)/2, V], diag[D(D+1)/2] from the raw dictionary U[D,V].
+BTVAE_API int btvae_dict_prepare(const float* U, float* Uhat, float* norms, float* UU, float* diag, int D, int V,
+                                 float marginal_std_lim, void* stream) {
+    BTVAE_REQUIRE(U && Uhat && norms && UU && diag, "dict_prepare: null pointer");
+    BTVAE_REQUIRE(D > 0 && D <= 64 && V > 0, "dict_prepare: D=%d must be in 1..64", D);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(dict_norm_kernel, dim3((V + 63) / 64), dim3(64), 0, s, U, Uhat, norms, D, V);
+    const size_t n = (size_t)(D * (D + 1) / 2) * V;
+    hipLaunchKernelGGL(dict_tables_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Uhat, UU, diag, D, V, marginal_std_lim * marginal_std_lim);
+    return check_launch("dict_prepare");
+}
+
+BTVAE_API int btvae_dict_grad(const float* M1, const float* Uhat, const float* norms, float* dU, int D, int V, int accumulate, void* stream) {
+    BTVAE_REQUIRE(M1 && Uhat && norms && dU, "dict_grad: null pointer");
+    BTVAE_REQUIRE(D > 0 && D <= 64, "dict_grad: D=%d must be in 1..64", D);
+    hipLaunchKernelGGL(dict_grad_kernel, dim3(V), dim3(64), 0, (hipStream_t)stream, M1, Uhat, norms, dU, D, V, accumulate);
+    return check_launch("dict_grad");
+}
+
+// Forward-only MVN log-density of rows given packed covariances Sp[rows, D(D+1)/2].
+BTVAE_API int btvae_mvn_rows_fwd(const float* Sp, const float* mu, const float* x, float* logp, int rows, int B, int D, void* stream) {
+    BTVAE_REQUIRE(Sp && mu && x && logp, "mvn_rows_fwd: null pointer");
+    BTVAE_REQUIRE(rows > 0 && B > 0 && D > 0 && D <= 64, "mvn_rows_fwd: bad shape rows=%d B=%d D=%d", rows, B, D);
+    const double np = 0.5 * D * (D + 1);
+    ProfScope ps(PK_MVN_ROWS, (hipStream_t)stream, rows * (double)D * D * D / 3.0, 4.0 * rows * (np + D + 1));
+    return launch_mvn<false>(D, Sp, mu, x, nullptr, nullptr, 0.f, logp, nullptr, nullptr, rows, B, (hipStream_t)stream);
+}
+
+// MVN log-density plus backward seeds: dmu_raw = g*alpha*dfac_mu and Pg (see kernel comment).
+BTVAE_API int btvae_mvn_rows_fwd_bwd(const float* Sp, const float* mu, const float* x, const float* dfac_mu, const float* g_rows,
+                                     float g_const, float* logp, float* dmu_raw, float* Pg, int rows, int B, int D, void* stream) {
+    BTVAE_REQUIRE(Sp && mu && x && dfac_mu && logp && dmu_raw && Pg, "mvn_rows_fwd_bwd: null pointer");
+    BTVAE_REQUIRE(rows > 0 && B > 0 && D > 0 && D <= 64, "mvn_rows_fwd_bwd: bad shape rows=%d B=%d D=%d", rows, B, D);
+    const double np = 0.5 * D * (D + 1);
+    ProfScope ps(PK_MVN_ROWS, (hipStream_t)stream, rows * 2.0 * D * D * D, 4.0 * rows * (2 * np + 3 * D + 1));
+    return launch_mvn<true>(D, Sp, mu, x, dfac_mu, g_rows, g_const, logp, dmu_raw, Pg, rows, B, (hipStream_t)stream);
+}
+
+BTVAE_API int btvae_elbo_scalars(const float* logp, int nlog, const float* klrow, int nkl, float beta, float* out4, void* stream) {
+    BTVAE_REQUIRE(logp && klrow && out4 && nlog > 0 && nkl > 0, "elbo_scalars: bad arguments");
+    ProfScope ps(PK_REDUCE, (hipStream_t)stream, 0, 4.0 * (nlog + nkl));
+    hipLaunchKernelGGL(elbo_scalars_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logp, nlog, klrow, nkl, beta, out4);
+    return check_launch("elbo_scalars");
+}
+
+BTVAE_API int btvae_iw_lse_update(const float* rll, const float* eps, const float* mu, const float* sigma, float* m_run, float* s_run,
+                                  int kc, int N, int L, int first, void* stream) {
+    BTVAE_REQUIRE(rll && eps && mu && sigma && m_run && s_run, "iw_lse_update: null pointer");
+    BTVAE_REQUIRE(kc > 0 && N > 0 && L > 0, "iw_lse_update: bad shape");
+    ProfScope ps(PK_REDUCE, (hipStream_t)stream, 0, 4.0 * ((double)kc * N * (L + 1) + 2.0 * N * L + 4.0 * N));
+    hipLaunchKernelGGL(iw_lse_update_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, rll, eps, mu, sigma, m_run, s_run, kc, N, L, first);
+    return check_launch("iw_lse_update");
+}
+
+BTVAE_API int btvae_iw_lse_finalize(const float* m_run, const float* s_run, float* ll, int N, int K, void* stream) {
+    BTVAE_REQUIRE(m_run && s_run && ll && N > 0 && K > 0, "iw_lse_finalize: bad arguments");
+    hipLaunchKernelGGL(iw_lse_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, m_run, s_run, ll, N, logf((float)K));
+    return check_launch("iw_lse_finalize");
+}

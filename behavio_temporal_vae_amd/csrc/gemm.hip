@@ -1,0 +1,434 @@
+// fp32 MFMA GEMM family for gfx950 (v_mfma_f32_32x32x2_f32, exact f32 fmaf-chain numerics).
+//
+// One kernel template serves the three operand layouts a Linear layer needs and the covariance
+// GEMMs of the dictionary-Gaussian likelihood:
+//   forward   Y[M,N]  = X[M,K] W[N,K]^T          A k-contiguous, B k-contiguous
+//   dgrad     dX[M,K] = dY[M,N] W[N,K]           A k-contiguous, B n-contiguous
+//   wgrad     dW[N,K] = dY[M,N]^T X[M,K]         A m-contiguous, B n-contiguous (reduction split over z)
+// Block tile 128x128x32, 256 threads = 4 waves (2x2), each wave a 64x64 tile = 2x2 MFMA tiles of
+// 32x32 (64 accumulator registers).  Global -> registers -> LDS staging, double-buffered LDS, one
+// barrier per k-tile.  LDS images mirror the global layout (no transposes while staging); the
+// k index fed to MFMA number q of a k-tile by lane half h is (q/4)*8 + 4h + q%4 for BOTH operands,
+// which makes the k-contiguous fragment a single 16-byte LDS read.  The f32 MFMA runs at the f32
+// vector rate (64 FLOP/clk/SIMD), so the kernel is MFMA-issue bound; LDS and L2 have >4x slack.
+#include "common.h"
+#include <algorithm>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDK = BK + 4;             // row stride (floats) of a k-contiguous LDS tile: 16-B slots 9 apart -> conflict-free b128
+constexpr int LDM = 128 + 4;            // row stride of an m/n-contiguous LDS tile
+constexpr int TILE_FLOATS = 128 * LDK;  // 4608 >= 32 * LDM
+
+enum { LAY_K = 0, LAY_M = 1 };
+enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_RELU_STATS = 2, EPI_RELU_AFFINE = 3, EPI_HEAD = 4, EPI_MUL = 5 };
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    int lda, ldb, ldc;
+    int M, N, K;
+    int kchunk;                 // reduction elements per blockIdx.z (multiple of BK)
+    size_t slab_stride;         // C elements between z slabs
+    const float* bias;          // [N]
+    const float* scale; const float* shift;   // [N]  (EPI_RELU_AFFINE; null = identity)
+    const float* R; int ldr;    // add-in [M,N]       (EPI_PLAIN / EPI_RELU_AFFINE; null = none)
+    float* C2; float* C3;       // EPI_HEAD: derivative factor, squared value (either may be null)
+    float* stats;               // EPI_RELU_STATS: [tiles_m][2][N] = per-tile column (mean, M2)
+    const float* E1; const float* E2; int lde;  // EPI_MUL
+    int act; float lo, hi;      // EPI_HEAD
+    int a_vec, b_vec;
+    int tiles_m, tiles_n;
+};
+
+template <int LAY>
+__device__ __forceinline__ void g2r(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int kend,
+                                    int vec, int tid, float4 (&st)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int f = tid + 256 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (LAY == LAY_K) {
+            const int r = f >> 3, c = (f & 7) << 2;
+            const int gr = row0 + r, gk = k0 + c;
+            if (gr < nrows && gk < kend) {
+                const float* src = P + (size_t)gr * ld + gk;
+                if (vec && gk + 3 < kend) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    v.x = src[0];
+                    if (gk + 1 < kend) v.y = src[1];
+                    if (gk + 2 < kend) v.z = src[2];
+                    if (gk + 3 < kend) v.w = src[3];
+                }
+            }
+        } else {
+            const int kr = f >> 5, c = (f & 31) << 2;
+            const int gk = k0 + kr, gm = row0 + c;
+            if (gk < kend && gm < nrows) {
+                const float* src = P + (size_t)gk * ld + gm;
+                if (vec && gm + 3 < nrows) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    v.x = src[0];
+                    if (gm + 1 < nrows) v.y = src[1];
+                    if (gm + 2 < nrows) v.z = src[2];
+                    if (gm + 3 < nrows) v.w = src[3];
+                }
+            }
+        }
+        st[q] = v;
+    }
+}
+
+template <int LAY>
+__device__ __forceinline__ void r2s(float* S, int tid, const float4 (&st)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int f = tid + 256 * q;
+        if (LAY == LAY_K) *reinterpret_cast<float4*>(S + (f >> 3) * LDK + ((f & 7) << 2)) = st[q];
+        else              *reinterpret_cast<float4*>(S + (f >> 5) * LDM + ((f & 31) << 2)) = st[q];
+    }
+}
+
+template <int LAY>
+__device__ __forceinline__ float4 frag(const float* S, int rc, int g, int lh) {
+    if (LAY == LAY_K) return *reinterpret_cast<const float4*>(S + rc * LDK + g * 8 + lh * 4);
+    const float* q = S + (g * 8 + lh * 4) * LDM + rc;
+    return make_float4(q[0], q[LDM], q[2 * LDM], q[3 * LDM]);
+}
+
+__device__ __forceinline__ float softplus5(float x) { return x > 5.f ? x : log1pf(expf(x)); }
+
+template <int AL, int BL, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2][2][TILE_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // Workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of tiles so
+    // the tiles that share an A row panel meet in one L2 (bijective for any tile count).
+    int bid = blockIdx.x;
+    {
+        const int nwg = p.tiles_m * p.tiles_n;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 sa[4], sb[4];
+    if (nk > 0) {
+        g2r<AL>(p.A, p.lda, m0, p.M, kbeg, kend, p.a_vec, tid, sa);
+        g2r<BL>(p.B, p.ldb, n0, p.N, kbeg, kend, p.b_vec, tid, sb);
+        r2s<AL>(smem[0][0], tid, sa);
+        r2s<BL>(smem[0][1], tid, sb);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        const bool more = t + 1 < nk;
+        const int k0 = kbeg + t * BK;
+        if (more) {
+            g2r<AL>(p.A, p.lda, m0, p.M, k0 + BK, kend, p.a_vec, tid, sa);
+            g2r<BL>(p.B, p.ldb, n0, p.N, k0 + BK, kend, p.b_vec, tid, sb);
+        }
+        const float* As = smem[cur][0];
+        const float* Bs = smem[cur][1];
+        const int krem = kend - k0;
+        const int ngroups = krem >= BK ? 4 : (krem + 7) >> 3;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < ngroups) {
+                float4 a[2], b[2];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) a[rb] = frag<AL>(As, wr * 64 + rb * 32 + li, g, lh);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) b[cb] = frag<BL>(Bs, wc * 64 + cb * 32 + li, g, lh);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb].x, b[cb].x, acc[rb][cb], 0, 0, 0);
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb].y, b[cb].y, acc[rb][cb], 0, 0, 0);
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb].z, b[cb].z, acc[rb][cb], 0, 0, 0);
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb].w, b[cb].w, acc[rb][cb], 0, 0, 0);
+                    }
+            }
+        }
+        if (more) {
+            r2s<AL>(smem[cur ^ 1][0], tid, sa);
+            r2s<BL>(smem[cur ^ 1][1], tid, sb);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulator element r of tile (rb,cb) is row (r&3)+8(r>>2)+4*lh, column li ----
+    float colv[2][3];   // per-column vectors: bias / scale / shift
+    int colg[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int col = n0 + wc * 64 + cb * 32 + li;
+        colg[cb] = col;
+        const bool ok = col < p.N;
+        colv[cb][0] = (EPI == EPI_BIAS || EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE || EPI == EPI_HEAD) && ok ? p.bias[col] : 0.f;
+        colv[cb][1] = (EPI == EPI_RELU_AFFINE && ok && p.scale) ? p.scale[col] : 1.f;
+        colv[cb][2] = (EPI == EPI_RELU_AFFINE && ok && p.shift) ? p.shift[col] : 0.f;
+    }
+    float* Cz = p.C + (size_t)blockIdx.z * p.slab_stride;
+
+    float st_n[2], st_mean[2], st_m2[2];   // EPI_RELU_STATS: this lane's (count, mean, M2) per column block
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int col = colg[cb];
+        float shiftK = 0.f, s = 0.f, q = 0.f, cnt = 0.f;
+        bool have = false;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const bool ok = row < p.M && col < p.N;
+                float v = acc[rb][cb][r];
+                if (EPI == EPI_PLAIN) {
+                    if (ok) {
+                        if (p.R) v += p.R[(size_t)row * p.ldr + col];
+                        Cz[(size_t)row * p.ldc + col] = v;
+                    }
+                } else if (EPI == EPI_BIAS) {
+                    if (ok) Cz[(size_t)row * p.ldc + col] = v + colv[cb][0];
+                } else if (EPI == EPI_RELU_STATS) {
+                    v = fmaxf(v + colv[cb][0], 0.f);
+                    if (ok) {
+                        Cz[(size_t)row * p.ldc + col] = v;
+                        if (!have) { shiftK = v; have = true; }
+                        const float d = v - shiftK;
+                        s += d; q += d * d; cnt += 1.f;
+                    }
+                } else if (EPI == EPI_RELU_AFFINE) {
+                    v = fmaxf(v + colv[cb][0], 0.f) * colv[cb][1] + colv[cb][2];
+                    if (ok) {
+                        if (p.R) v += p.R[(size_t)row * p.ldr + col];
+                        Cz[(size_t)row * p.ldc + col] = v;
+                    }
+                } else if (EPI == EPI_HEAD) {
+                    const float raw = v + colv[cb][0];
+                    float val, df;
+                    if (p.act == 0) {            // clamp
+                        val = fminf(fmaxf(raw, p.lo), p.hi);
+                        df = (raw >= p.lo && raw <= p.hi) ? 1.f : 0.f;
+                    } else if (p.act == 1) {     // clamp(softplus(raw; threshold 5))
+                        const float sp = softplus5(raw);
+                        val = fminf(fmaxf(sp, p.lo), p.hi);
+                        df = (sp >= p.lo && sp <= p.hi) ? (raw > 5.f ? 1.f : 1.f / (1.f + expf(-raw))) : 0.f;
+                    } else {                     // clamp(relu(raw))
+                        const float rl = fmaxf(raw, 0.f);
+                        val = fminf(fmaxf(rl, p.lo), p.hi);
+                        df = (raw > 0.f && rl >= p.lo && rl <= p.hi) ? 1.f : 0.f;
+                    }
+                    if (ok) {
+                        const size_t o = (size_t)row * p.ldc + col;
+                        Cz[o] = val;
+                        if (p.C2) p.C2[o] = df;
+                        if (p.C3) p.C3[o] = val * val;
+                    }
+                } else if (EPI == EPI_MUL) {
+                    if (ok) {
+                        const size_t e = (size_t)row * p.lde + col;
+                        Cz[(size_t)row * p.ldc + col] = v * p.E1[e] * p.E2[e];
+                    }
+                }
+            }
+        }
+        if (EPI == EPI_RELU_STATS) {
+            float mean = 0.f, m2 = 0.f;
+            if (cnt > 0.f) { mean = shiftK + s / cnt; m2 = fmaxf(q - s * s / cnt, 0.f); }
+            // merge the two lane halves (rows +4): Chan's pairwise update
+            const float on = __shfl_xor(cnt, 32, 64), om = __shfl_xor(mean, 32, 64), o2 = __shfl_xor(m2, 32, 64);
+            const float n = cnt + on;
+            if (n > 0.f) {
+                const float dlt = om - mean;
+                m2 = m2 + o2 + dlt * dlt * (cnt * on / n);
+                mean = (cnt * mean + on * om) / n;
+            }
+            st_n[cb] = n; st_mean[cb] = mean; st_m2[cb] = m2;
+        }
+    }
+
+    if (EPI == EPI_RELU_STATS) {
+        float* red = &smem[0][0][0];   // [wr][3][128]; the k-loop's last barrier has retired all tile reads
+        if (lh == 0) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int c = wc * 64 + cb * 32 + li;
+                red[(wr * 3 + 0) * 128 + c] = st_n[cb];
+                red[(wr * 3 + 1) * 128 + c] = st_mean[cb];
+                red[(wr * 3 + 2) * 128 + c] = st_m2[cb];
+            }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            const float na = red[0 * 128 + tid], ma = red[1 * 128 + tid], qa = red[2 * 128 + tid];
+            const float nb = red[3 * 128 + tid], mb = red[4 * 128 + tid], qb = red[5 * 128 + tid];
+            const float n = na + nb;
+            float mean = ma, m2 = qa;
+            if (nb > 0.f) {
+                const float dlt = mb - ma;
+                m2 = qa + qb + dlt * dlt * (na * nb / n);
+                mean = (na * ma + nb * mb) / n;
+            }
+            p.stats[((size_t)tile_m * 2 + 0) * p.N + n0 + tid] = mean;
+            p.stats[((size_t)tile_m * 2 + 1) * p.N + n0 + tid] = m2;
+        }
+    }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t n, int nslab, size_t stride, int accumulate) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        float v = accumulate ? out[i] : 0.f;
+        for (int z = 0; z < nslab; ++z) v += slabs[(size_t)z * stride + i];
+        out[i] = v;
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int AL, int BL, int EPI>
+int launch(GemmArgs a, int splits, hipStream_t s, const char* what) {
+    BTVAE_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "%s: empty problem M=%d N=%d K=%d", what, a.M, a.N, a.K);
+    BTVAE_REQUIRE(a.A && a.B && a.C, "%s: null operand", what);
+    BTVAE_REQUIRE(a.ldc >= a.N, "%s: ldc %d < N %d", what, a.ldc, a.N);
+    BTVAE_REQUIRE(a.lda >= (AL == LAY_K ? a.K : a.M), "%s: lda %d too small", what, a.lda);
+    BTVAE_REQUIRE(a.ldb >= (BL == LAY_K ? a.K : a.N), "%s: ldb %d too small", what, a.ldb);
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    a.a_vec = (a.lda % 4 == 0) && aligned16(a.A);
+    a.b_vec = (a.ldb % 4 == 0) && aligned16(a.B);
+    if (splits < 1) splits = 1;
+    a.kchunk = (((a.K + splits - 1) / splits) + BK - 1) / BK * BK;
+    splits = (a.K + a.kchunk - 1) / a.kchunk;
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)splits);
+    hipLaunchKernelGGL((gemm_f32_mfma<AL, BL, EPI>), grid, dim3(256), 0, s, a);
+    return btvae::check_launch(what);
+}
+
+int pick_splits(int tiles, int K, size_t ws_floats, size_t out_elems) {
+    int want = (1024 + tiles - 1) / tiles;            // aim at ~4 workgroups per CU
+    int maxk = std::max(1, K / (4 * BK));              // keep >= 4 k-tiles per split
+    int splits = std::max(1, std::min(want, maxk));
+    if (splits > 1) {
+        size_t fit = out_elems ? ws_floats / out_elems : 0;
+        if (fit < 2) return 1;
+        splits = (int)std::min<size_t>((size_t)splits, fit);
+    }
+    return splits;
+}
+
+}  // namespace
+
+using namespace btvae;
+
+// Y = relu(X W^T + b), plus per-128-row-tile column (mean, M2) partials for BatchNorm statistics.
+BTVAE_API int btvae_linear_relu_stats_fwd(const float* X, int ldx, const float* W, const float* b, float* Y,
+                                          float* stat_partials, int M, int K, int N, void* stream) {
+    BTVAE_REQUIRE(b && stat_partials, "linear_relu_stats_fwd: null bias/stats");
+    GemmArgs a{}; a.A = X; a.lda = ldx; a.B = W; a.ldb = K; a.C = Y; a.ldc = N; a.M = M; a.N = N; a.K = K;
+    a.bias = b; a.stats = stat_partials;
+    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    return launch<LAY_K, LAY_K, EPI_RELU_STATS>(a, 1, (hipStream_t)stream, "linear_relu_stats_fwd");
+}
+
+// Out = relu(X W^T + b) * scale + shift (+ R): Linear+ReLU+eval-mode BatchNorm(+residual) in one pass.
+BTVAE_API int btvae_linear_relu_affine_fwd(const float* X, int ldx, const float* W, const float* b, const float* scale,
+                                           const float* shift, const float* R, float* Out, int M, int K, int N, void* stream) {
+    BTVAE_REQUIRE(b, "linear_relu_affine_fwd: null bias");
+    GemmArgs a{}; a.A = X; a.lda = ldx; a.B = W; a.ldb = K; a.C = Out; a.ldc = N; a.M = M; a.N = N; a.K = K;
+    a.bias = b; a.scale = scale; a.shift = shift; a.R = R; a.ldr = N;
+    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    return launch<LAY_K, LAY_K, EPI_RELU_AFFINE>(a, 1, (hipStream_t)stream, "linear_relu_affine_fwd");
+}
+
+// Head output layer: raw = X W^T + b; act 0: clamp, 1: clamp(softplus), 2: clamp(relu).
+// Out = value, Dfac = d value / d raw (may be null), Sq = value^2 (may be null).
+BTVAE_API int btvae_linear_head_fwd(const float* X, int ldx, const float* W, const float* b, int act, float lo, float hi,
+                                    float* Out, float* Dfac, float* Sq, int M, int K, int N, void* stream) {
+    BTVAE_REQUIRE(b, "linear_head_fwd: null bias");
+    BTVAE_REQUIRE(act >= 0 && act <= 2, "linear_head_fwd: unknown activation %d", act);
+    GemmArgs a{}; a.A = X; a.lda = ldx; a.B = W; a.ldb = K; a.C = Out; a.ldc = N; a.M = M; a.N = N; a.K = K;
+    a.bias = b; a.C2 = Dfac; a.C3 = Sq; a.act = act; a.lo = lo; a.hi = hi;
+    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    return launch<LAY_K, LAY_K, EPI_HEAD>(a, 1, (hipStream_t)stream, "linear_head_fwd");
+}
+
+// dX[M,K] = dY[M,N] W[N,K] (+ R[M,K]).
+BTVAE_API int btvae_linear_dgrad(const float* dY, const float* W, const float* R, float* dX, int lddx, int M, int N, int K, void* stream) {
+    GemmArgs a{}; a.A = dY; a.lda = N; a.B = W; a.ldb = K; a.C = dX; a.ldc = lddx; a.M = M; a.N = K; a.K = N;
+    a.R = R; a.ldr = lddx;
+    ProfScope ps(PK_GEMM_DGRAD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * N + (double)N * K + (double)M * K));
+    return launch<LAY_K, LAY_M, EPI_PLAIN>(a, 1, (hipStream_t)stream, "linear_dgrad");
+}
+
+// C[M,N] (+)= A^T B with A stored [K][M] (lda) and B stored [K][N] (ldb); the reduction is split over
+// workgroups into slabs held in `ws` and summed by a second kernel.  accumulate != 0 adds to C.
+BTVAE_API int btvae_matmul_tn(const float* A, int lda, const float* B, int ldb, float* C, float* ws, long long ws_floats,
+                              int M, int N, int K, int accumulate, int prof_kind, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs a{}; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.ldc = N; a.M = M; a.N = N; a.K = K;
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const size_t out_elems = (size_t)M * N;
+    int splits = pick_splits(tiles, K, ws ? (size_t)ws_floats : 0, out_elems);
+    ProfScope ps(prof_kind, s, 2.0 * M * N * K, 4.0 * ((double)K * M + (double)K * N + (double)M * N));
+    if (splits == 1 && !accumulate) {
+        a.C = C;
+        return launch<LAY_M, LAY_M, EPI_PLAIN>(a, 1, s, "matmul_tn");
+    }
+    BTVAE_REQUIRE(ws && (size_t)ws_floats >= out_elems, "matmul_tn: workspace of %lld floats too small for %zu", ws_floats, out_elems);
+    a.C = ws; a.slab_stride = out_elems;
+    int rc = launch<LAY_M, LAY_M, EPI_PLAIN>(a, splits, s, "matmul_tn");
+    if (rc) return rc;
+    const int kchunk = (((K + splits - 1) / splits) + BK - 1) / BK * BK;
+    const int nslab = (K + kchunk - 1) / kchunk;
+    const int blocks = (int)std::min<size_t>((out_elems + 255) / 256, 2048);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, C, out_elems, nslab, out_elems, accumulate);
+    return check_launch("matmul_tn.reduce");
+}
+
+// dW[N,K] (+)= dY[M,N]^T X[M,K].
+BTVAE_API int btvae_linear_wgrad(const float* dY, const float* X, int ldx, float* dW, float* ws, long long ws_floats,
+                                 int M, int N, int K, int accumulate, void* stream) {
+    return btvae_matmul_tn(dY, N, X, ldx, dW, ws, ws_floats, N, K, M, accumulate, PK_GEMM_WGRAD, stream);
+}
+
+// C[M,N] = A[M,K] B[N,K]^T + bias[N].
+BTVAE_API int btvae_matmul_nt_bias(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc,
+                                   int M, int N, int K, void* stream) {
+    BTVAE_REQUIRE(bias, "matmul_nt_bias: null bias");
+    GemmArgs a{}; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.bias = bias;
+    ProfScope ps(PK_GEMM_MVN, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    return launch<LAY_K, LAY_K, EPI_BIAS>(a, 1, (hipStream_t)stream, "matmul_nt_bias");
+}
+
+// C[M,N] = (A[M,K] B[K,N]) * E1[M,N] * E2[M,N].
+BTVAE_API int btvae_matmul_nn_mul(const float* A, int lda, const float* B, int ldb, const float* E1, const float* E2, int lde,
+                                  float* C, int ldc, int M, int N, int K, void* stream) {
+    BTVAE_REQUIRE(E1 && E2, "matmul_nn_mul: null multiplier");
+    GemmArgs a{}; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    a.E1 = E1; a.E2 = E2; a.lde = lde;
+    ProfScope ps(PK_GEMM_MVN, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + 3.0 * M * N));
+    return launch<LAY_K, LAY_M, EPI_MUL>(a, 1, (hipStream_t)stream, "matmul_nn_mul");
+}

@@ -1,0 +1,172 @@
+// Conditional-Gaussian step of pseudo-Gibbs imputation: condition the decoder's multivariate normal
+// on the observed coordinates, draw the missing ones, and the equal-weight mixture log-likelihood of
+// held-out targets.  One wave per profile; lane i holds row i of the covariance in registers.
+//
+// Sweeping the covariance on the observed pivots (Gauss-Jordan steps restricted to k in O) leaves
+//   A[u][o] = -Sigma_uo Sigma_oo^-1     and     A[u][u'] = Sigma_uu - Sigma_uo Sigma_oo^-1 Sigma_ou
+// i.e. the regression coefficients and the conditional covariance in place.  A forward LDL^T
+// elimination over the unobserved pivots then yields the Cholesky factor columns one at a time,
+// which is all a draw mean + L eps needs.
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+template <int DP>
+__global__ __launch_bounds__(256) void cond_mvn_kernel(const float* __restrict__ Sp, const float* __restrict__ mu,
+                                                       const float* __restrict__ x, const float* __restrict__ eps,
+                                                       unsigned long long obs_mask, const int* __restrict__ un_pos,
+                                                       float* __restrict__ samp, float* __restrict__ cmean, float* __restrict__ ccov,
+                                                       int rows, int D, int U) {
+    constexpr int NPMAX = DP * (DP + 1) / 2;
+    __shared__ float sh[4][NPMAX];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row_raw = blockIdx.x * 4 + w;
+    const bool live = row_raw < rows;
+    const int row = live ? row_raw : rows - 1;
+    const int NP = D * (D + 1) / 2;
+    const int i = lane;
+    for (int p = lane; p < NP; p += 64) sh[w][p] = Sp[(size_t)row * NP + p];
+    __syncthreads();
+    float a[DP];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+        float v = (i == j) ? 1.f : 0.f;
+        if (i < D && j < D) { const int mx = max(i, j), mn = min(i, j); v = sh[w][mx * (mx + 1) / 2 + mn]; }
+        a[j] = v;
+    }
+    const bool is_obs = i < D && ((obs_mask >> i) & 1ull);
+    const bool is_un = i < D && !is_obs;
+    const float mui = i < D ? mu[(size_t)row * D + i] : 0.f;
+    const float ri = is_obs ? x[(size_t)row * D + i] - mui : 0.f;    // residual of observed coordinates
+
+    // sweep on observed pivots
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+        if (k < D && ((obs_mask >> k) & 1ull)) {
+            const float piv = readlane_f(a[k], k);
+            const float rp = 1.f / piv;
+            const float gk = (i == k) ? (1.f - rp) : a[k] * rp;
+#pragma unroll
+            for (int j = 0; j < DP; ++j) {
+                if (j != k) { const float s = readlane_f(a[j], k); a[j] = fmaf(-gk, s, a[j]); }
+            }
+            a[k] = (i == k) ? rp : -gk;
+        }
+    }
+    // conditional mean of unobserved lane i: mu_i - sum_{k in O} A[i][k] r_k
+    float cm = mui;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+        const float rk = readlane_f(ri, k);
+        if (k < D && ((obs_mask >> k) & 1ull)) cm = fmaf(-a[k], rk, cm);
+    }
+    const int myu = is_un ? un_pos[i] : 0;           // position of coordinate i among the unobserved ones
+    if (live && is_un) {
+        cmean[(size_t)row * U + myu] = cm;
+#pragma unroll
+        for (int j = 0; j < DP; ++j)
+            if (j < D && !((obs_mask >> j) & 1ull)) ccov[((size_t)row * U + myu) * U + un_pos[j]] = a[j];
+    }
+    // draw: forward elimination over the unobserved pivots, sample_i = cm_i + sum_k L[i][k] sqrt(d_k) eps_k
+    const float ei = is_un ? eps[(size_t)row * U + myu] : 0.f;
+    float sm = cm;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+        if (k < D && !((obs_mask >> k) & 1ull)) {
+            const float piv = readlane_f(a[k], k);
+            const float rp = 1.f / piv;
+            const float ek = readlane_f(ei, k) * sqrtf(piv);
+            const float f = (is_un && i > k) ? a[k] * rp : ((i == k) ? 1.f : 0.f);
+            sm = fmaf(f, ek, sm);
+            const float fe = (is_un && i > k) ? f : 0.f;
+#pragma unroll
+            for (int j = k + 1; j < DP; ++j) { const float s = readlane_f(a[j], k); a[j] = fmaf(-fe, s, a[j]); }
+        }
+    }
+    if (live && is_un) samp[(size_t)row * U + myu] = sm;
+}
+
+__global__ void masked_scatter_kernel(float* __restrict__ dst, const long long* __restrict__ idx, const float* __restrict__ src, long long n) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[idx[t]] = src[t];
+}
+
+// out[b] = logsumexp_k logp[k][b] - log K
+__global__ void lse_over_k_kernel(const float* __restrict__ logp, float* __restrict__ out, int K, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float m = -INFINITY;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, logp[(size_t)k * B + b]);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += expf(logp[(size_t)k * B + b] - m);
+    out[b] = m + logf(s) - logf((float)K);
+}
+
+// full [rows][D][D] covariances -> packed lower triangles [rows][D(D+1)/2]
+__global__ void pack_lower_kernel(const float* __restrict__ full, float* __restrict__ packed, long long rows, int D) {
+    const int NP = D * (D + 1) / 2;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * NP) return;
+    const long long row = t / NP; const int p = (int)(t % NP);
+    int d = (int)((sqrtf(8.f * p + 1.f) - 1.f) * 0.5f);
+    while ((d + 1) * (d + 2) / 2 <= p) ++d;
+    while (d * (d + 1) / 2 > p) --d;
+    const int e = p - d * (d + 1) / 2;
+    packed[t] = full[(row * D + d) * D + e];
+}
+
+}  // namespace
+
+using namespace btvae;
+
+// Per row: condition N(mu, Sigma) (Sigma packed [rows, D(D+1)/2]) on the coordinates set in obs_mask
+// (bit d = coordinate d observed, values taken from x[rows, D]), write the conditional mean [rows,U],
+// covariance [rows,U,U] and one draw mean + chol(cov) eps[rows,U].  un_pos[d] = rank of coordinate d
+// among the unobserved ones (device array of D ints).
+BTVAE_API int btvae_cond_mvn_sample(const float* Sp, const float* mu, const float* x, const float* eps, unsigned long long obs_mask,
+                                    const int* un_pos, float* samples, float* cond_mean, float* cond_cov, int rows, int D, int U,
+                                    void* stream) {
+    BTVAE_REQUIRE(Sp && mu && x && eps && un_pos && samples && cond_mean && cond_cov, "cond_mvn_sample: null pointer");
+    BTVAE_REQUIRE(rows > 0 && D > 0 && D <= 64 && U > 0 && U <= D, "cond_mvn_sample: bad shape rows=%d D=%d U=%d", rows, D, U);
+    int nobs = 0;
+    for (int d = 0; d < D; ++d) nobs += (int)((obs_mask >> d) & 1ull);
+    BTVAE_REQUIRE(nobs == D - U, "cond_mvn_sample: mask has %d observed coordinates, expected %d", nobs, D - U);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((rows + 3) / 4), block(256);
+    ProfScope ps(PK_MVN_ROWS, s, rows * 2.0 * D * D * D, 4.0 * rows * (0.5 * D * (D + 1) + 2.0 * D + U * (U + 3.0)));
+#define BTVAE_COND_CASE(DPV) hipLaunchKernelGGL((cond_mvn_kernel<DPV>), grid, block, 0, s, Sp, mu, x, eps, obs_mask, un_pos, samples, cond_mean, cond_cov, rows, D, U)
+    if (D <= 8) BTVAE_COND_CASE(8);
+    else if (D <= 16) BTVAE_COND_CASE(16);
+    else if (D <= 24) BTVAE_COND_CASE(24);
+    else if (D <= 32) BTVAE_COND_CASE(32);
+    else if (D <= 48) BTVAE_COND_CASE(48);
+    else BTVAE_COND_CASE(64);
+#undef BTVAE_COND_CASE
+    return check_launch("cond_mvn_sample");
+}
+
+// dst[idx[t]] = src[t], t < n: the row-major masked write-back of a Gibbs sweep.
+BTVAE_API int btvae_masked_scatter(float* dst, const long long* idx, const float* src, long long n, void* stream) {
+    BTVAE_REQUIRE(dst && idx && src && n > 0, "masked_scatter: bad arguments");
+    hipLaunchKernelGGL(masked_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, idx, src, n);
+    return check_launch("masked_scatter");
+}
+
+BTVAE_API int btvae_lse_over_k(const float* logp, float* out, int K, int B, void* stream) {
+    BTVAE_REQUIRE(logp && out && K > 0 && B > 0, "lse_over_k: bad arguments");
+    hipLaunchKernelGGL(lse_over_k_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, logp, out, K, B);
+    return check_launch("lse_over_k");
+}
+
+BTVAE_API int btvae_pack_lower(const float* full, float* packed, long long rows, int D, void* stream) {
+    BTVAE_REQUIRE(full && packed && rows > 0 && D > 0, "pack_lower: bad arguments");
+    const long long n = rows * (D * (D + 1) / 2);
+    hipLaunchKernelGGL(pack_lower_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, full, packed, rows, D);
+    return check_launch("pack_lower");
+}

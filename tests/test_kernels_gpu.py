@@ -1,0 +1,356 @@
+"""GPU: every C-ABI kernel entry point against an fp64 torch/CPU restatement of the same op.
+Tolerances are fp32 round-off for the reduction length involved (stated per test)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from behavio_temporal_vae_amd import _native as nv  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    d = torch.device("cuda:0")
+    nv.ensure_device(d)
+    return d
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale)
+
+
+def close(got, ref, rtol, atol=0.0, what=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    err = (got - ref).abs()
+    lim = atol + rtol * ref.abs()
+    bad = err > lim
+    assert not bad.any(), f"{what}: max err {err.max().item():.3e}, worst ratio {(err / (lim + 1e-300)).max().item():.2f}"
+
+
+P = nv.ptr
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 52, 1000), (256, 1000, 1000), (129, 40, 72), (64, 7, 5)])
+def test_linear_relu_stats(dev, M, K, N):
+    X, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3, scale=0.1)
+    Xd, Wd, bd = (t.float().to(dev) for t in (X, W, b))
+    Y = torch.empty(M, N, device=dev)
+    tiles = (M + 127) // 128
+    part = torch.empty(tiles, 2, N, device=dev)
+    nv.call("btvae_linear_relu_stats_fwd", P(Xd), K, P(Wd), P(bd), P(Y), P(part), M, K, N)
+    ref = torch.relu(Xd.cpu().double() @ Wd.cpu().double().t() + bd.cpu().double())
+    close(Y, ref, 2e-6, 2e-6 * math.sqrt(K), "y")
+    mean, invstd = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    rm, rv = torch.zeros(N, device=dev), torch.ones(N, device=dev)
+    nv.call("btvae_bn_stats_finalize", P(part), tiles, M, N, P(mean), P(invstd), P(rm), P(rv), 0.1, 1e-5)
+    yr = Y.cpu().double()
+    close(mean, yr.mean(0), 1e-5, 1e-6, "mean")
+    close(invstd, 1 / torch.sqrt(yr.var(0, unbiased=False) + 1e-5), 2e-5, 0, "invstd")
+    close(rm, 0.1 * yr.mean(0), 1e-5, 1e-6, "running_mean")
+    close(rv, 0.9 + 0.1 * yr.var(0, unbiased=True), 2e-5, 0, "running_var")
+
+
+def test_linear_relu_affine_and_head(dev):
+    M, K, N = 200, 96, 100
+    X, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.3), rnd(N, seed=3)
+    sc, sh, R = rnd(N, seed=4), rnd(N, seed=5), rnd(M, N, seed=6)
+    d = [t.float().to(dev) for t in (X, W, b, sc, sh, R)]
+    out = torch.empty(M, N, device=dev)
+    nv.call("btvae_linear_relu_affine_fwd", P(d[0]), K, P(d[1]), P(d[2]), P(d[3]), P(d[4]), P(d[5]), P(out), M, K, N)
+    c = [t.cpu().double() for t in d]
+    ref = torch.relu(c[0] @ c[1].t() + c[2]) * c[3] + c[4] + c[5]
+    close(out, ref, 1e-5, 2e-5, "affine")
+    raw = c[0] @ c[1].t() + c[2]
+    for act, lo, hi in ((0, -0.5, 0.8), (1, 0.05, 1.0), (2, 1e-4, 0.62)):
+        o, df, sq = (torch.empty(M, N, device=dev) for _ in range(3))
+        nv.call("btvae_linear_head_fwd", P(d[0]), K, P(d[1]), P(d[2]), act, lo, hi, P(o), P(df), P(sq), M, K, N)
+        rr = raw.clone().requires_grad_(True)
+        if act == 0:
+            val = rr.clamp(lo, hi)
+        elif act == 1:
+            val = torch.nn.functional.softplus(rr, beta=1, threshold=5).clamp(lo, hi)
+        else:
+            val = torch.relu(rr).clamp(lo, hi)
+        val.sum().backward()
+        close(o, val, 1e-5, 2e-5, f"head{act}")
+        close(sq, val ** 2, 1e-5, 2e-5, f"head{act}.sq")
+        # the derivative factor may differ where raw sits within round-off of a clamp edge
+        edge = ((raw - lo).abs() < 1e-4) | ((raw - hi).abs() < 1e-4) | (raw.abs() < 1e-4)
+        if act == 1:
+            sp = torch.nn.functional.softplus(raw, beta=1, threshold=5)
+            edge = ((sp - lo).abs() < 1e-4) | ((sp - hi).abs() < 1e-4) | ((raw - 5).abs() < 1e-4)
+        dd = (df.cpu().double() - rr.grad).abs()
+        assert dd[~edge].max() < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 1000, 52), (4096, 100, 1000), (130, 48, 1000), (70, 9, 33)])
+def test_dgrad_wgrad(dev, M, N, K):
+    dY, W, X, R = rnd(M, N, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(M, K, seed=3), rnd(M, K, seed=4)
+    d = [t.float().to(dev) for t in (dY, W, X, R)]
+    c = [t.cpu().double() for t in d]
+    dX = torch.empty(M, K, device=dev)
+    nv.call("btvae_linear_dgrad", P(d[0]), P(d[1]), P(d[3]), P(dX), K, M, N, K)
+    close(dX, c[0] @ c[1] + c[3], 2e-6, 3e-6 * math.sqrt(N), "dgrad")
+    ws = torch.empty(16 * N * K, device=dev)
+    dW = torch.full((N, K), 0.5, device=dev)
+    nv.call("btvae_linear_wgrad", P(d[0]), P(d[2]), K, P(dW), P(ws), ws.numel(), M, N, K, 0)
+    close(dW, c[0].t() @ c[2], 2e-6, 3e-6 * math.sqrt(M), "wgrad")
+    nv.call("btvae_linear_wgrad", P(d[0]), P(d[2]), K, P(dW), P(ws), ws.numel(), M, N, K, 1)
+    close(dW, 2 * (c[0].t() @ c[2]), 2e-6, 6e-6 * math.sqrt(M), "wgrad accumulate")
+
+
+def test_matmul_bias_and_mul(dev):
+    M, K, N = 260, 100, 1176
+    A, B, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    d = [t.float().to(dev) for t in (A, B, bias)]
+    C = torch.empty(M, N, device=dev)
+    nv.call("btvae_matmul_nt_bias", P(d[0]), K, P(d[1]), K, P(d[2]), P(C), N, M, N, K)
+    close(C, d[0].cpu().double() @ d[1].cpu().double().t() + d[2].cpu().double(), 2e-6, 3e-5, "nt_bias")
+    E1, E2 = rnd(M, K, seed=4).float().to(dev), rnd(M, K, seed=5).float().to(dev)
+    C2 = torch.empty(M, K, device=dev)
+    nv.call("btvae_matmul_nn_mul", P(C), N, P(d[1]), K, P(E1), P(E2), K, P(C2), K, M, K, N)
+    ref = (C.cpu().double() @ d[1].cpu().double()) * E1.cpu().double() * E2.cpu().double()
+    close(C2, ref, 1e-5, 1e-3, "nn_mul")
+
+
+@pytest.mark.parametrize("M,N", [(1000, 1000), (77, 36), (300, 30)])
+def test_batchnorm_fwd_bwd(dev, M, N):
+    Yr = torch.relu(rnd(M, N, seed=1)).float()
+    G, R = rnd(M, N, seed=2).float(), rnd(M, N, seed=3).float()
+    gam, bet = (rnd(N, seed=4) * 0.5 + 1).float(), rnd(N, seed=5).float()
+    y = Yr.double().requires_grad_(True)
+    g64, b64 = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    mean = y.mean(0); var = y.var(0, unbiased=False)
+    out = (y - mean) / torch.sqrt(var + 1e-5) * g64 + b64 + R.double()
+    # forward apply
+    d = {k: v.to(dev) for k, v in dict(Y=Yr, G=G, R=R, gam=gam, bet=bet).items()}
+    mean_d = mean.detach().float().to(dev); inv_d = (1 / torch.sqrt(var.detach() + 1e-5)).float().to(dev)
+    o = torch.empty(M, N, device=dev)
+    nv.call("btvae_bn_apply_fwd", P(d["Y"]), P(mean_d), P(inv_d), P(d["gam"]), P(d["bet"]), P(d["R"]), P(o), M, N)
+    close(o, out, 1e-5, 1e-5, "bn fwd")
+    # backward: reference goes through relu as well (y = relu(pre))
+    pre = rnd(M, N, seed=1).requires_grad_(True)
+    y2 = torch.relu(pre)
+    m2 = y2.mean(0); v2 = y2.var(0, unbiased=False)
+    out2 = (y2 - m2) / torch.sqrt(v2 + 1e-5) * g64 + b64
+    out2.backward(G.double())
+    nscr = nv.lib().btvae_bn_relu_bwd_scratch(M, N)
+    scr = torch.empty(nscr, device=dev)
+    dgam, dbet, dbias = (torch.zeros(N, device=dev) for _ in range(3))
+    dpre = torch.empty(M, N, device=dev)
+    nv.call("btvae_bn_relu_bwd", P(d["G"]), P(d["Y"]), P(mean_d), P(inv_d), P(d["gam"]), P(dgam), P(dbet), P(dbias), P(dpre), P(scr), M, N, 0)
+    s = math.sqrt(M)
+    close(dpre, pre.grad, 1e-4, 2e-6, "dpre")
+    close(dgam, g64.grad, 1e-5, 3e-6 * s, "dgamma")
+    close(dbet, b64.grad, 1e-5, 3e-6 * s, "dbeta")
+    close(dbias, pre.grad.sum(0), 1e-5, 3e-6 * s, "dbias")
+    cs = torch.empty(nv.lib().btvae_strip_chunks(M) * N, device=dev)
+    outc = torch.ones(N, device=dev)
+    nv.call("btvae_colsum", P(d["G"]), P(outc), P(cs), M, N, 1)
+    close(outc, 1 + G.double().sum(0), 1e-5, 3e-6 * s, "colsum")
+
+
+@pytest.mark.parametrize("threeD", [False, True])
+def test_reparam_kl(dev, threeD):
+    B, S, L, C = 37, 5, 48, 4
+    R = S * B if threeD else B
+    Sl = 1 if threeD else S
+    mu, sg = rnd(R, L, seed=1).float(), (rnd(R, L, seed=2).abs() * 0.5 + 0.05).float()
+    eps = rnd(Sl * R, L, seed=3).float()
+    cond = rnd(B, S, C, seed=4).float() if threeD else rnd(B, C, seed=4).float()
+    d = [t.to(dev) for t in (mu, sg, eps, cond)]
+    zc = torch.empty(Sl * R, L + C, device=dev); kl = torch.empty(R, device=dev)
+    if threeD:
+        cdiv, hi, lo = B, C, S * C
+    else:
+        cdiv, hi, lo = R, 0, C
+    nv.call("btvae_reparam_kl_fwd", P(d[0]), P(d[1]), P(d[2]), None, P(d[3]), P(zc), P(kl), R, Sl, L, C, cdiv, hi, lo, 0, 0)
+    z_ref = (mu.double() + sg.double() * eps.double().view(Sl, R, L)).view(Sl * R, L)
+    if threeD:
+        c_ref = cond.double().transpose(0, 1).reshape(R, C)
+    else:
+        c_ref = cond.double().unsqueeze(0).expand(S, B, C).reshape(S * B, C)
+    close(zc[:, :L], z_ref, 1e-6, 1e-6, "z")
+    close(zc[:, L:], c_ref, 0, 0, "cond copy")
+    kl_ref = (0.5 * (sg.double() ** 2 + mu.double() ** 2 - 1 - torch.log(sg.double() ** 2))).sum(-1)
+    close(kl, kl_ref, 1e-5, 1e-5, "kl")
+    # backward
+    dzc = rnd(Sl * R, L + C, seed=5).float().to(dev)
+    dfm, dfs = (rnd(R, L, seed=6) > 0).float().to(dev), torch.rand(R, L, generator=torch.Generator().manual_seed(7)).to(dev)
+    dm, ds = torch.empty(R, L, device=dev), torch.empty(R, L, device=dev)
+    w = 0.7 / R
+    nv.call("btvae_reparam_kl_bwd", P(dzc), P(d[2]), P(d[0]), P(d[1]), P(dfm), P(dfs), P(dm), P(ds), R, Sl, L, C, w)
+    dz = dzc.cpu().double()[:, :L].view(Sl, R, L)
+    close(dm, (dz.sum(0) + w * mu.double()) * dfm.cpu().double(), 1e-5, 1e-6, "dmu")
+    close(ds, ((dz * eps.double().view(Sl, R, L)).sum(0) + w * (sg.double() - 1 / sg.double())) * dfs.cpu().double(), 1e-5, 1e-5, "dsigma")
+    # in-kernel Philox draws: standard normal moments, and reproducible
+    e1, e2 = torch.empty(Sl * R, L, device=dev), torch.empty(Sl * R, L, device=dev)
+    nv.call("btvae_reparam_kl_fwd", P(d[0]), P(d[1]), None, P(e1), P(d[3]), P(zc), P(kl), R, Sl, L, C, cdiv, hi, lo, 2112, 7)
+    nv.call("btvae_reparam_kl_fwd", P(d[0]), P(d[1]), None, P(e2), P(d[3]), P(zc), P(kl), R, Sl, L, C, cdiv, hi, lo, 2112, 7)
+    assert torch.equal(e1, e2)
+    assert abs(e1.mean().item()) < 0.05 and abs(e1.std().item() - 1) < 0.05
+
+
+@pytest.mark.parametrize("D,V,rows,B", [(48, 100, 301, 43), (6, 9, 50, 10), (24, 100, 130, 130)])
+def test_dictgauss_mvn(dev, D, V, rows, B):
+    U = rnd(D, V, seed=1)
+    sig = (rnd(rows, V, seed=2).abs() * 0.3 + 1e-3).clamp(max=0.62)
+    mu, x = rnd(rows, D, seed=3), rnd(B, D, seed=4)
+    m = 0.1
+    NP = D * (D + 1) // 2
+    Ud = U.float().to(dev)
+    Uh, nr, UU, dg = torch.empty(D, V, device=dev), torch.empty(V, device=dev), torch.empty(NP, V, device=dev), torch.empty(NP, device=dev)
+    nv.call("btvae_dict_prepare", P(Ud), P(Uh), P(nr), P(UU), P(dg), D, V, m)
+    # fp64 reference with autograd
+    U64 = Ud.cpu().double().requires_grad_(True)
+    s64 = sig.float().double().requires_grad_(True)
+    mu64 = mu.float().double().requires_grad_(True)
+    x64 = x.float().double()
+    Uh64 = U64 / torch.linalg.norm(U64, dim=0, keepdim=True)
+    Sg = Uh64 * s64[:, None, :]
+    Sigma = Sg @ Sg.transpose(-1, -2) + torch.eye(D, dtype=torch.float64) * m * m
+    xr = x64[torch.arange(rows) % B]
+    lp = torch.distributions.MultivariateNormal(mu64, covariance_matrix=Sigma).log_prob(xr)
+    g = -1.0 / rows
+    (g * lp.sum()).backward()
+    close(Uh, Uh64, 1e-6, 1e-7, "Uhat")
+    # covariance build
+    s2 = (sig.float() ** 2).to(dev)
+    Sp = torch.empty(rows, NP, device=dev)
+    nv.call("btvae_matmul_nt_bias", P(s2), V, P(UU), V, P(dg), P(Sp), NP, rows, NP, V)
+    tri = torch.tril_indices(D, D)
+    close(Sp, Sigma.detach()[:, tri[0], tri[1]], 1e-5, 1e-6, "Sigma packed")
+    mud, xd = mu.float().to(dev), x.float().to(dev)
+    lpf = torch.empty(rows, device=dev)
+    nv.call("btvae_mvn_rows_fwd", P(Sp), P(mud), P(xd), P(lpf), rows, B, D)
+    close(lpf, lp, 2e-5, 1e-4, "logp fwd-only")
+    dfm = torch.ones(rows, D, device=dev)
+    lpb, dmu, Pg = torch.empty(rows, device=dev), torch.empty(rows, D, device=dev), torch.empty(rows, NP, device=dev)
+    nv.call("btvae_mvn_rows_fwd_bwd", P(Sp), P(mud), P(xd), P(dfm), None, g, P(lpb), P(dmu), P(Pg), rows, B, D)
+    close(lpb, lp, 2e-5, 1e-4, "logp")
+    gs = mu64.grad.abs().max().item()
+    close(dmu, mu64.grad, 1e-4, 2e-5 * gs, "dmu")
+    # dsigma = (Pg @ UU) * sigma * dfac
+    sd_, ones = sig.float().to(dev), torch.ones(rows, V, device=dev)
+    dsg = torch.empty(rows, V, device=dev)
+    nv.call("btvae_matmul_nn_mul", P(Pg), NP, P(UU), V, P(sd_), P(ones), V, P(dsg), V, rows, V, NP)
+    close(dsg, s64.grad, 2e-4, 3e-5 * s64.grad.abs().max().item(), "dsigma")
+    # dU via M1 = Pg^T sigma^2
+    ws = torch.empty(8 * NP * V, device=dev)
+    M1 = torch.empty(NP, V, device=dev)
+    nv.call("btvae_matmul_tn", P(Pg), NP, P(s2), V, P(M1), P(ws), ws.numel(), NP, V, rows, 0, 3)
+    dU = torch.zeros(D, V, device=dev)
+    nv.call("btvae_dict_grad", P(M1), P(Uh), P(nr), P(dU), D, V, 0)
+    close(dU, U64.grad, 2e-4, 3e-5 * U64.grad.abs().max().item(), "dU")
+
+
+def test_diag_loglik(dev):
+    rows, B, D = 90, 30, 48
+    mu, sg, x = rnd(rows, D, seed=1), rnd(rows, D, seed=2).abs() * 0.5 + 0.1, rnd(B, D, seed=3)
+    m64, s64 = mu.float().double().requires_grad_(True), sg.float().double().requires_grad_(True)
+    xr = x.float().double()[torch.arange(rows) % B]
+    lp = (-0.5 * math.log(2 * math.pi) - torch.log(s64) - 0.5 * ((xr - m64) / s64) ** 2).sum(-1)
+    g = -1.0 / rows
+    (g * lp.sum()).backward()
+    d = [t.float().to(dev) for t in (x, mu, sg)]
+    ones = torch.ones(rows, D, device=dev)
+    o, dm, ds = torch.empty(rows, device=dev), torch.empty(rows, D, device=dev), torch.empty(rows, D, device=dev)
+    nv.call("btvae_diag_gauss_loglik", P(d[0]), P(d[1]), P(d[2]), P(o), P(ones), P(ones), P(dm), P(ds), None, g, rows, B, D)
+    close(o, lp, 1e-5, 1e-4, "logp")
+    close(dm, m64.grad, 1e-4, 1e-6, "dmu")
+    close(ds, s64.grad, 1e-4, 1e-5, "dsigma")
+
+
+def test_elbo_scalars_and_iw_lse(dev):
+    lp, kl = rnd(5000, seed=1).float() * 30 - 100, rnd(300, seed=2).abs().float() * 10
+    out = torch.empty(4, device=dev)
+    lpd, kld = lp.to(dev), kl.to(dev)
+    nv.call("btvae_elbo_scalars", P(lpd), 5000, P(kld), 300, 0.7, P(out))
+    rll, k = lp.double().mean(), kl.double().mean()
+    close(out, torch.stack([-(rll - 0.7 * k), rll - k, rll, k]), 1e-6, 1e-6, "elbo scalars")
+    K, N, L = 11, 50, 24
+    mu, sg = rnd(N, L, seed=3).float(), (rnd(N, L, seed=4).abs() * 0.5 + 0.05).float()
+    eps, rl = rnd(K, N, L, seed=5).float(), (rnd(K, N, seed=6) * 20 - 50).float()
+    z = mu.double() + sg.double() * eps.double()
+    nlp = lambda t, m, s: (-0.5 * math.log(2 * math.pi) - torch.log(s) - 0.5 * ((t - m) / s) ** 2).sum(-1)
+    w = -nlp(z, mu.double(), sg.double()) + rl.double() + nlp(z, torch.zeros_like(z), torch.ones_like(z))
+    ref = torch.logsumexp(w, 0) - math.log(K)
+    m_run, s_run, ll = (torch.empty(N, device=dev) for _ in range(3))
+    d = [t.to(dev) for t in (rl, eps, mu, sg)]
+    nv.call("btvae_iw_lse_update", P(d[0][:4].contiguous()), P(d[1][:4].contiguous()), P(d[2]), P(d[3]), P(m_run), P(s_run), 4, N, L, 1)
+    nv.call("btvae_iw_lse_update", P(d[0][4:].contiguous()), P(d[1][4:].contiguous()), P(d[2]), P(d[3]), P(m_run), P(s_run), K - 4, N, L, 0)
+    nv.call("btvae_iw_lse_finalize", P(m_run), P(s_run), P(ll), N, K)
+    close(ll, ref, 1e-5, 1e-4, "iw lse")
+
+
+def test_clip_adam(dev):
+    n = 100003
+    p0, g = rnd(n, seed=1).float(), (rnd(n, seed=2) * 0.05).float()
+    pr = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.Adam([pr], lr=1e-3, weight_decay=1e-5)
+    # arenas padded to a multiple of 4 floats, 16-byte aligned
+    p, gd, m, v = (torch.zeros(n + 1, device=dev) for _ in range(4))
+    p[:n] = p0.to(dev)
+    part = torch.empty(512, dtype=torch.float64, device=dev)
+    nrm = torch.empty(1, device=dev)
+    for step in range(1, 4):
+        gs = g * step
+        pr.grad = gs.double().clone()
+        tot = torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        gd[:n] = gs.to(dev)
+        nv.call("btvae_grad_sumsq", P(gd), n, P(part))
+        nv.call("btvae_clip_adam_step", P(p), P(gd), P(m), P(v), n, P(part), 1.0, 1e-3, 0.9, 0.999, 1e-8, 1e-5, step, P(nrm))
+        close(nrm, tot.reshape(1), 1e-6, 0, "norm")
+        close(p[:n], pr.detach(), 1e-6, 2e-7, f"params step {step}")
+
+
+def test_cond_mvn(dev):
+    rows, D, Uc = 70, 48, 24
+    NP = D * (D + 1) // 2
+    A = rnd(rows, D, D, seed=1) * 0.3
+    Sigma = A @ A.transpose(-1, -2) + torch.eye(D, dtype=torch.float64) * 0.01
+    Sigma = Sigma.float().double()
+    mu, x, eps = rnd(rows, D, seed=2).float(), rnd(rows, D, seed=3).float(), rnd(rows, Uc, seed=4).float()
+    obs = list(range(0, 12)) + list(range(36, 48))      # a non-suffix window
+    un = [i for i in range(D) if i not in obs]
+    tri = torch.tril_indices(D, D)
+    Sp = Sigma[:, tri[0], tri[1]].float().to(dev)
+    mask = sum(1 << i for i in obs)
+    un_pos = torch.zeros(D, dtype=torch.int32)
+    for r_, i in enumerate(un):
+        un_pos[i] = r_
+    samp, cm, cc = torch.empty(rows, Uc, device=dev), torch.empty(rows, Uc, device=dev), torch.empty(rows, Uc, Uc, device=dev)
+    mud, xd, epsd, upd = mu.to(dev), x.to(dev), eps.to(dev), un_pos.to(dev)
+    nv.call("btvae_cond_mvn_sample", P(Sp), P(mud), P(xd), P(epsd), mask, P(upd), P(samp), P(cm), P(cc), rows, D, Uc)
+    S64 = Sp.cpu().double()
+    full = torch.zeros(rows, D, D, dtype=torch.float64)
+    full[:, tri[0], tri[1]] = S64
+    full = full + full.transpose(-1, -2) - torch.diag_embed(torch.diagonal(full, dim1=-2, dim2=-1))
+    Soo, Suo, Suu = full[:, obs][:, :, obs], full[:, un][:, :, obs], full[:, un][:, :, un]
+    Aco = Suo @ torch.linalg.inv(Soo)
+    mean = mu.double()[:, un] + (Aco @ (x.double()[:, obs] - mu.double()[:, obs])[..., None])[..., 0]
+    cov = Suu - Aco @ Suo.transpose(-1, -2)
+    close(cm, mean, 2e-4, 2e-4, "cond mean")
+    close(cc, cov, 2e-4, 2e-5, "cond cov")
+    sref = mean + (torch.linalg.cholesky(cov) @ eps.double()[..., None])[..., 0]
+    close(samp, sref, 2e-4, 2e-4, "cond sample")
+    # scatter + pack + lse
+    dst = torch.zeros(rows, D, device=dev)
+    idx = (torch.arange(rows)[:, None] * D + torch.tensor(un)[None, :]).reshape(-1).to(dev)
+    nv.call("btvae_masked_scatter", P(dst), P(idx), P(samp), rows * Uc)
+    assert torch.equal(dst[:, un], samp) and torch.count_nonzero(dst[:, obs]) == 0
+    pk = torch.empty(rows, Uc * (Uc + 1) // 2, device=dev)
+    nv.call("btvae_pack_lower", P(cc), P(pk), rows, Uc)
+    t2 = torch.tril_indices(Uc, Uc)
+    assert torch.equal(pk, cc[:, t2[0], t2[1]])
+    lp = (rnd(7, rows, seed=9) * 10).float().to(dev)
+    o = torch.empty(rows, device=dev)
+    nv.call("btvae_lse_over_k", P(lp), P(o), 7, rows)
+    close(o, torch.logsumexp(lp.cpu().double(), 0) - math.log(7), 1e-6, 1e-5, "lse over k")
