@@ -29,6 +29,7 @@ _SIGS = {
     "btvae_linear_wgrad": [P, P, I, P, P, LL, I, I, I, I, P],
     "btvae_matmul_tn": [P, I, P, I, P, P, LL, I, I, I, I, I, P],
     "btvae_matmul_nt_bias": [P, I, P, I, P, P, I, I, I, I, P],
+    "btvae_matmul_nt_add": [P, I, P, I, P, I, P, I, I, I, I, P],
     "btvae_matmul_nn_mul": [P, I, P, I, P, P, I, P, I, I, I, I, P],
     "btvae_bn_stats_finalize": [P, I, I, I, P, P, P, P, F, F, P],
     "btvae_bn_fold_eval": [P, P, P, P, F, P, P, I, P],

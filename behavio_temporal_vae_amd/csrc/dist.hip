@@ -206,35 +206,39 @@ __global__ __launch_bounds__(256) void mvn_rows_kernel(const float* __restrict__
     float r = 0.f;
     if (i < D) r = x[(size_t)(row % B) * D + i] - mu[(size_t)row * D + i];
 
+    // The pivot loop is a real loop (small code, stays in the instruction cache): instead of indexing the
+    // register row by k, the row is rotated left by one column per step, so the pivot column is always
+    // register 0 and after DP steps the columns are back in place.
     float logdet = 0.f, maha = 0.f, alpha = 0.f;
     if (BWD) {
-#pragma unroll
+#pragma unroll 1
         for (int k = 0; k < DP; ++k) {
-            const float piv = readlane_f(a[k], k);
+            const float piv = readlane_f(a[0], k);
             logdet += logf(piv);
             const float rp = 1.f / piv;
-            const float gk = (i == k) ? (1.f - rp) : a[k] * rp;
+            const float gk = (i == k) ? (1.f - rp) : a[0] * rp;
+            const float last = (i == k) ? rp : -gk;
 #pragma unroll
-            for (int j = 0; j < DP; ++j) {
-                if (j != k) { const float s = readlane_f(a[j], k); a[j] = fmaf(-gk, s, a[j]); }
-            }
-            a[k] = (i == k) ? rp : -gk;
+            for (int j = 1; j < DP; ++j) { const float s = readlane_f(a[j], k); a[j - 1] = fmaf(-gk, s, a[j]); }
+            a[DP - 1] = last;
         }
 #pragma unroll
         for (int j = 0; j < DP; ++j) alpha = fmaf(a[j], readlane_f(r, j), alpha);
         maha = wave_sum(r * alpha);
     } else {
-#pragma unroll
+#pragma unroll 1
         for (int k = 0; k < DP; ++k) {
-            const float piv = readlane_f(a[k], k);
+            const float piv = readlane_f(a[0], k);
             logdet += logf(piv);
             const float rp = 1.f / piv;
             const float yk = readlane_f(r, k);
             maha = fmaf(yk * yk, rp, maha);
-            const float f = (i > k) ? a[k] * rp : 0.f;
+            const float f = (i > k) ? a[0] * rp : 0.f;
             r = fmaf(-f, yk, r);
+            const float keep = a[0];
 #pragma unroll
-            for (int j = k + 1; j < DP; ++j) { const float s = readlane_f(a[j], k); a[j] = fmaf(-f, s, a[j]); }
+            for (int j = 1; j < DP; ++j) { const float s = readlane_f(a[j], k); a[j - 1] = fmaf(-f, s, a[j]); }
+            a[DP - 1] = keep;
         }
     }
     const float lp = -0.5f * ((float)D * LOG_2PI + maha) - 0.5f * logdet;

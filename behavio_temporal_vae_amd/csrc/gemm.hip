@@ -43,9 +43,37 @@ struct GemmArgs {
     int tiles_m, tiles_n;
 };
 
+// Vector path (rows 16-byte aligned, contiguous extent and leading dimension multiples of 4): one predicated
+// 16-byte load per chunk into a zero-initialised register, no use of the data before the LDS write, so all
+// 8 loads of a k-tile stay in flight behind the MFMAs of the current tile.
 template <int LAY>
+__device__ __forceinline__ void g2r_vec(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int kend,
+                                        int tid, float4 (&st)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int f = tid + 256 * q;
+        bool ok;
+        size_t off;
+        if (LAY == LAY_K) {
+            const int gr = row0 + (f >> 3), gk = k0 + ((f & 7) << 2);
+            ok = gr < nrows && gk + 3 < kend;
+            off = (size_t)gr * ld + gk;
+        } else {
+            const int gk = k0 + (f >> 5), gm = row0 + ((f & 31) << 2);
+            ok = gk < kend && gm + 3 < nrows;
+            off = (size_t)gk * ld + gm;
+        }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float4*>(P + off);
+        st[q] = v;
+    }
+}
+
+template <int LAY, bool VEC>
 __device__ __forceinline__ void g2r(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int kend,
-                                    int vec, int tid, float4 (&st)[4]) {
+                                    int tid, float4 (&st)[4]) {
+    if (VEC) { g2r_vec<LAY>(P, ld, row0, nrows, k0, kend, tid, st); return; }
+    const int vec = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int f = tid + 256 * q;
@@ -100,7 +128,7 @@ __device__ __forceinline__ float4 frag(const float* S, int rc, int g, int lh) {
 
 __device__ __forceinline__ float softplus5(float x) { return x > 5.f ? x : log1pf(expf(x)); }
 
-template <int AL, int BL, int EPI>
+template <int AL, int BL, int EPI, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2][2][TILE_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -131,8 +159,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs p) {
 
     float4 sa[4], sb[4];
     if (nk > 0) {
-        g2r<AL>(p.A, p.lda, m0, p.M, kbeg, kend, p.a_vec, tid, sa);
-        g2r<BL>(p.B, p.ldb, n0, p.N, kbeg, kend, p.b_vec, tid, sb);
+        g2r<AL, VEC>(p.A, p.lda, m0, p.M, kbeg, kend, tid, sa);
+        g2r<BL, VEC>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, sb);
         r2s<AL>(smem[0][0], tid, sa);
         r2s<BL>(smem[0][1], tid, sb);
     }
@@ -143,8 +171,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs p) {
         const bool more = t + 1 < nk;
         const int k0 = kbeg + t * BK;
         if (more) {
-            g2r<AL>(p.A, p.lda, m0, p.M, k0 + BK, kend, p.a_vec, tid, sa);
-            g2r<BL>(p.B, p.ldb, n0, p.N, k0 + BK, kend, p.b_vec, tid, sb);
+            g2r<AL, VEC>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, sa);
+            g2r<BL, VEC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, sb);
         }
         const float* As = smem[cur][0];
         const float* Bs = smem[cur][1];
@@ -184,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs p) {
         const int col = n0 + wc * 64 + cb * 32 + li;
         colg[cb] = col;
         const bool ok = col < p.N;
-        colv[cb][0] = (EPI == EPI_BIAS || EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE || EPI == EPI_HEAD) && ok ? p.bias[col] : 0.f;
+        colv[cb][0] = (EPI == EPI_BIAS || EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE || EPI == EPI_HEAD) && ok && p.bias ? p.bias[col] : 0.f;
         colv[cb][1] = (EPI == EPI_RELU_AFFINE && ok && p.scale) ? p.scale[col] : 1.f;
         colv[cb][2] = (EPI == EPI_RELU_AFFINE && ok && p.shift) ? p.shift[col] : 0.f;
     }
@@ -209,7 +237,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs p) {
                         Cz[(size_t)row * p.ldc + col] = v;
                     }
                 } else if (EPI == EPI_BIAS) {
-                    if (ok) Cz[(size_t)row * p.ldc + col] = v + colv[cb][0];
+                    if (ok) {
+                        v += colv[cb][0];
+                        if (p.R) v += p.R[(size_t)row * p.ldr + col];
+                        Cz[(size_t)row * p.ldc + col] = v;
+                    }
                 } else if (EPI == EPI_RELU_STATS) {
                     v = fmaxf(v + colv[cb][0], 0.f);
                     if (ok) {
@@ -317,13 +349,15 @@ int launch(GemmArgs a, int splits, hipStream_t s, const char* what) {
     BTVAE_REQUIRE(a.ldb >= (BL == LAY_K ? a.K : a.N), "%s: ldb %d too small", what, a.ldb);
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
-    a.a_vec = (a.lda % 4 == 0) && aligned16(a.A);
-    a.b_vec = (a.ldb % 4 == 0) && aligned16(a.B);
+    // the vector path treats every 4-float chunk as all-or-nothing, so the contiguous extent must be a multiple of 4
+    a.a_vec = (a.lda % 4 == 0) && aligned16(a.A) && ((AL == LAY_K ? a.K : a.M) % 4 == 0);
+    a.b_vec = (a.ldb % 4 == 0) && aligned16(a.B) && ((BL == LAY_K ? a.K : a.N) % 4 == 0);
     if (splits < 1) splits = 1;
     a.kchunk = (((a.K + splits - 1) / splits) + BK - 1) / BK * BK;
     splits = (a.K + a.kchunk - 1) / a.kchunk;
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)splits);
-    hipLaunchKernelGGL((gemm_f32_mfma<AL, BL, EPI>), grid, dim3(256), 0, s, a);
+    if (a.a_vec && a.b_vec) hipLaunchKernelGGL((gemm_f32_mfma<AL, BL, EPI, true>), grid, dim3(256), 0, s, a);
+    else                    hipLaunchKernelGGL((gemm_f32_mfma<AL, BL, EPI, false>), grid, dim3(256), 0, s, a);
     return btvae::check_launch(what);
 }
 
@@ -421,6 +455,14 @@ BTVAE_API int btvae_matmul_nt_bias(const float* A, int lda, const float* B, int 
     GemmArgs a{}; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.bias = bias;
     ProfScope ps(PK_GEMM_MVN, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     return launch<LAY_K, LAY_K, EPI_BIAS>(a, 1, (hipStream_t)stream, "matmul_nt_bias");
+}
+
+// C[M,N] = A[M,K] B[N,K]^T + R[M,N]  (R may be null).
+BTVAE_API int btvae_matmul_nt_add(const float* A, int lda, const float* B, int ldb, const float* R, int ldr, float* C, int ldc,
+                                  int M, int N, int K, void* stream) {
+    GemmArgs a{}; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.R = R; a.ldr = ldr;
+    ProfScope ps(PK_GEMM_MVN, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + 2.0 * M * N));
+    return launch<LAY_K, LAY_K, EPI_BIAS>(a, 1, (hipStream_t)stream, "matmul_nt_add");
 }
 
 // C[M,N] = (A[M,K] B[K,N]) * E1[M,N] * E2[M,N].

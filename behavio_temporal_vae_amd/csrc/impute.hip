@@ -45,19 +45,21 @@ __global__ __launch_bounds__(256) void cond_mvn_kernel(const float* __restrict__
     const float mui = i < D ? mu[(size_t)row * D + i] : 0.f;
     const float ri = is_obs ? x[(size_t)row * D + i] - mui : 0.f;    // residual of observed coordinates
 
-    // sweep on observed pivots
-#pragma unroll
+    // sweep on observed pivots.  Real loop with the register row rotated left by one column per step
+    // (pivot column always in register 0; after DP steps the columns are back in place).
+#pragma unroll 1
     for (int k = 0; k < DP; ++k) {
-        if (k < D && ((obs_mask >> k) & 1ull)) {
-            const float piv = readlane_f(a[k], k);
+        const bool piv_obs = k < D && ((obs_mask >> k) & 1ull);
+        float gk = 0.f, last = a[0];
+        if (piv_obs) {
+            const float piv = readlane_f(a[0], k);
             const float rp = 1.f / piv;
-            const float gk = (i == k) ? (1.f - rp) : a[k] * rp;
-#pragma unroll
-            for (int j = 0; j < DP; ++j) {
-                if (j != k) { const float s = readlane_f(a[j], k); a[j] = fmaf(-gk, s, a[j]); }
-            }
-            a[k] = (i == k) ? rp : -gk;
+            gk = (i == k) ? (1.f - rp) : a[0] * rp;
+            last = (i == k) ? rp : -gk;
         }
+#pragma unroll
+        for (int j = 1; j < DP; ++j) { const float s = readlane_f(a[j], k); a[j - 1] = fmaf(-gk, s, a[j]); }
+        a[DP - 1] = last;
     }
     // conditional mean of unobserved lane i: mu_i - sum_{k in O} A[i][k] r_k
     float cm = mui;
@@ -76,18 +78,21 @@ __global__ __launch_bounds__(256) void cond_mvn_kernel(const float* __restrict__
     // draw: forward elimination over the unobserved pivots, sample_i = cm_i + sum_k L[i][k] sqrt(d_k) eps_k
     const float ei = is_un ? eps[(size_t)row * U + myu] : 0.f;
     float sm = cm;
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < DP; ++k) {
-        if (k < D && !((obs_mask >> k) & 1ull)) {
-            const float piv = readlane_f(a[k], k);
+        const bool piv_un = k < D && !((obs_mask >> k) & 1ull);
+        float fe = 0.f;
+        const float keep = a[0];
+        if (piv_un) {
+            const float piv = readlane_f(a[0], k);
             const float rp = 1.f / piv;
             const float ek = readlane_f(ei, k) * sqrtf(piv);
-            const float f = (is_un && i > k) ? a[k] * rp : ((i == k) ? 1.f : 0.f);
-            sm = fmaf(f, ek, sm);
-            const float fe = (is_un && i > k) ? f : 0.f;
-#pragma unroll
-            for (int j = k + 1; j < DP; ++j) { const float s = readlane_f(a[j], k); a[j] = fmaf(-fe, s, a[j]); }
+            fe = (is_un && i > k) ? a[0] * rp : 0.f;
+            sm = fmaf((i == k) ? 1.f : fe, ek, sm);
         }
+#pragma unroll
+        for (int j = 1; j < DP; ++j) { const float s = readlane_f(a[j], k); a[j - 1] = fmaf(-fe, s, a[j]); }
+        a[DP - 1] = keep;
     }
     if (live && is_un) samp[(size_t)row * U + myu] = sm;
 }

@@ -1,0 +1,358 @@
+"""Host-side sequencing of the HIP kernels for one conditional-VAE step.
+
+The engine owns no parameters: it walks the module tree of a distribution network (same layout as
+the reference's ``ParameterizerNN``, src/submodels.py:41-69), and for every Linear(+ReLU+BatchNorm)
+unit issues the matching C-ABI calls on the current HIP stream.  torch only provides device buffers.
+
+Forward of one unit in train mode:  GEMM(bias+ReLU, column-statistics epilogue) -> statistics
+finalize -> BatchNorm apply (+ residual).  Eval mode folds BatchNorm into the GEMM epilogue.
+Backward: BatchNorm/ReLU backward (two streaming passes) -> wgrad GEMM (split reduction) -> dgrad
+GEMM whose epilogue adds the residual / second-consumer gradient.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _native as nv
+
+P = nv.ptr
+BN_EPS_DEFAULT = 1e-5
+
+
+@dataclass
+class Unit:
+    """Linear (+ReLU+BatchNorm[+Dropout]) unit of a network."""
+    lin: torch.nn.Linear
+    bn: Optional[torch.nn.BatchNorm1d]
+    act: bool            # ReLU (and BN when present) follow the Linear
+    residual: bool
+    dropout_p: float = 0.0
+
+
+@dataclass
+class Saved:
+    x_in: torch.Tensor
+    y: Optional[torch.Tensor] = None
+    mean: Optional[torch.Tensor] = None
+    invstd: Optional[torch.Tensor] = None
+
+
+class NetPlan:
+    """Ordered units of one distribution network and its output non-linearities."""
+
+    def __init__(self, dist):
+        blocks = dist.parameterizer.block_dict
+        self.dist = dist
+        self.trunk = [self._unit(blocks["input"].input_layer, False)]
+        self.trunk += [self._unit(seq, True) for seq in blocks["input"].middle_layers]
+        self.trunk.append(self._unit(blocks["input"].output_layer, False))
+        self.heads: Dict[str, List[Unit]] = {}
+        for name in dist.parameterizer.dist_params:
+            blk = blocks[name]
+            units = [self._unit(blk.input_layer, False)]
+            units += [self._unit(seq, True) for seq in blk.middle_layers]
+            units.append(self._unit(blk.output_layer, False))
+            self.heads[name] = units
+        self.in_dim = self.trunk[0].lin.in_features
+
+    @staticmethod
+    def _unit(seq, residual) -> Unit:
+        lin = seq[0]
+        bn, act, p = None, False, 0.0
+        for m in list(seq)[1:]:
+            if isinstance(m, torch.nn.ReLU):
+                act = True
+            elif isinstance(m, torch.nn.BatchNorm1d):
+                bn = m
+            elif isinstance(m, torch.nn.Dropout):
+                p = m.p
+        return Unit(lin, bn, act, residual, p)
+
+    def bn_modules(self):
+        for u in self.trunk + [u for h in self.heads.values() for u in h]:
+            if u.bn is not None:
+                yield u.bn
+
+
+class Workspace:
+    """Reusable device scratch (split-reduction slabs, BatchNorm partials, norm partials)."""
+
+    def __init__(self):
+        self.bufs: Dict[tuple, torch.Tensor] = {}
+
+    def get(self, key: str, numel: int, device, dtype=torch.float32) -> torch.Tensor:
+        k = (key, str(device), dtype)
+        t = self.bufs.get(k)
+        if t is None or t.numel() < numel:
+            t = torch.empty(max(numel, 1), device=device, dtype=dtype)
+            self.bufs[k] = t
+        return t
+
+
+WS = Workspace()
+WGRAD_WS_FLOATS = 32 * 1024 * 1024
+
+
+def _check_train_supported(u: Unit, train: bool):
+    if train and u.dropout_p > 0.0:
+        raise NotImplementedError("train-mode dropout is not implemented in the HIP path (use dropout: false, or eval mode)")
+    if train and u.act and u.bn is None:
+        raise NotImplementedError("training without batch normalisation is not implemented in the HIP path")
+
+
+def unit_forward(u: Unit, x: torch.Tensor, train: bool, saved: Optional[List[Saved]]) -> torch.Tensor:
+    """One Linear->ReLU->BatchNorm(->+x) unit (src/submodels.py:15-21,30-33) or a bare Linear."""
+    M, K = x.shape
+    N = u.lin.out_features
+    dev = x.device
+    W, b = u.lin.weight, u.lin.bias
+    assert u.act, "bare Linear units are head outputs; use head_forward"
+    _check_train_supported(u, train)
+    out = torch.empty(M, N, device=dev)
+    if u.bn is not None and train:
+        tiles = (M + 127) // 128
+        y = torch.empty(M, N, device=dev)
+        part = WS.get("bnpart", tiles * 2 * N, dev)
+        nv.call("btvae_linear_relu_stats_fwd", P(x), K, P(W), P(b), P(y), P(part), M, K, N)
+        mean, invstd = torch.empty(N, device=dev), torch.empty(N, device=dev)
+        track = u.bn.track_running_stats and u.bn.running_mean is not None
+        mom = u.bn.momentum if u.bn.momentum is not None else 0.1
+        nv.call("btvae_bn_stats_finalize", P(part), tiles, M, N, P(mean), P(invstd),
+                P(u.bn.running_mean) if track else None, P(u.bn.running_var) if track else None, float(mom), float(u.bn.eps))
+        nv.call("btvae_bn_apply_fwd", P(y), P(mean), P(invstd), P(u.bn.weight), P(u.bn.bias), P(x) if u.residual else None, P(out), M, N)
+        if saved is not None:
+            saved.append(Saved(x, y, mean, invstd))
+    else:
+        scale = shift = None
+        if u.bn is not None:
+            scale, shift = torch.empty(N, device=dev), torch.empty(N, device=dev)
+            nv.call("btvae_bn_fold_eval", P(u.bn.weight), P(u.bn.bias), P(u.bn.running_mean), P(u.bn.running_var), float(u.bn.eps), P(scale), P(shift), N)
+        nv.call("btvae_linear_relu_affine_fwd", P(x), K, P(W), P(b), P(scale), P(shift), P(x) if u.residual else None, P(out), M, K, N)
+    return out
+
+
+def head_forward(u: Unit, x: torch.Tensor, act: int, lo: float, hi: float, want_dfac: bool, want_sq: bool):
+    """Head output Linear fused with its clamp / softplus / relu non-linearity
+    (src/submodels.py:102-104,156-157).  Returns (value, dfac or None, value^2 or None)."""
+    M, K = x.shape
+    N = u.lin.out_features
+    val = torch.empty(M, N, device=x.device)
+    dfac = torch.empty(M, N, device=x.device) if want_dfac else None
+    sq = torch.empty(M, N, device=x.device) if want_sq else None
+    nv.call("btvae_linear_head_fwd", P(x), K, P(u.lin.weight), P(u.lin.bias), act, float(lo), float(hi), P(val), P(dfac), P(sq), M, K, N)
+    return val, dfac, sq
+
+
+@dataclass
+class NetTape:
+    trunk: List[Saved] = field(default_factory=list)
+    heads: Dict[str, List[Saved]] = field(default_factory=dict)
+    head_in: Dict[str, torch.Tensor] = field(default_factory=dict)   # input of each head's output Linear
+    dfac: Dict[str, torch.Tensor] = field(default_factory=dict)
+
+
+def net_forward(plan: NetPlan, x: torch.Tensor, train: bool, tape: Optional[NetTape], head_specs: Dict[str, tuple], want_sq=()):
+    """Whole ParameterizerNN + output non-linearities.  head_specs[name] = (act, lo, hi).
+    Returns {name: value}, {name: value^2} (for names in want_sq)."""
+    h = x
+    for u in plan.trunk:
+        h = unit_forward(u, h, train, tape.trunk if tape is not None else None)
+    out, sqs = {}, {}
+    for name, units in plan.heads.items():
+        t = h
+        sv = [] if tape is not None else None
+        for u in units[:-1]:
+            t = unit_forward(u, t, train, sv)
+        act, lo, hi = head_specs[name]
+        val, dfac, sq = head_forward(units[-1], t, act, lo, hi, tape is not None, name in want_sq)
+        out[name] = val
+        if sq is not None:
+            sqs[name] = sq
+        if tape is not None:
+            tape.heads[name] = sv
+            tape.head_in[name] = t
+            tape.dfac[name] = dfac
+    return out, sqs
+
+
+def _grad_view(p: torch.nn.Parameter) -> torch.Tensor:
+    if p.grad is None:
+        raise RuntimeError("parameter has no gradient buffer (model arena not initialised)")
+    return p.grad
+
+
+def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.Tensor], need_dx: bool, accumulate: bool):
+    """Backward of a ReLU+BN unit.  g = dL/d(out).  Returns dL/d(x_in) (+ add_to, + g for residual units)."""
+    M, N = g.shape
+    K = sv.x_in.shape[1]
+    dev = g.device
+    scr = WS.get("bnbwd", nv.lib().btvae_bn_relu_bwd_scratch(M, N), dev)
+    dpre = torch.empty(M, N, device=dev)
+    nv.call("btvae_bn_relu_bwd", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)),
+            P(_grad_view(u.lin.bias)), P(dpre), P(scr), M, N, int(accumulate))
+    ws = WS.get("wgrad", WGRAD_WS_FLOATS, dev)
+    nv.call("btvae_linear_wgrad", P(dpre), P(sv.x_in), K, P(_grad_view(u.lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
+    if not need_dx:
+        return None
+    r = None
+    if u.residual and add_to is not None:
+        raise RuntimeError("residual unit with a second gradient consumer is not a layout this engine builds")
+    if u.residual:
+        r = g
+    elif add_to is not None:
+        r = add_to
+    dx = torch.empty(M, K, device=dev)
+    nv.call("btvae_linear_dgrad", P(dpre), P(u.lin.weight), P(r), P(dx), K, M, N, K)
+    return dx
+
+
+def net_backward(plan: NetPlan, tape: NetTape, draw: Dict[str, torch.Tensor], need_input_grad: bool, accumulate: bool = False):
+    """Backward through heads and trunk given dL/d(raw head outputs).  Parameter gradients are written
+    (or accumulated) into the ``.grad`` views of the model's gradient arena."""
+    g_trunk = None
+    for name, units in plan.heads.items():
+        d = draw[name]
+        M, N = d.shape
+        dev = d.device
+        last = units[-1]
+        t_in = tape.head_in[name]
+        K = t_in.shape[1]
+        cs = WS.get("colsum", nv.lib().btvae_strip_chunks(M) * N, dev)
+        nv.call("btvae_colsum", P(d), P(_grad_view(last.lin.bias)), P(cs), M, N, int(accumulate))
+        ws = WS.get("wgrad", WGRAD_WS_FLOATS, dev)
+        nv.call("btvae_linear_wgrad", P(d), P(t_in), K, P(_grad_view(last.lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
+        g = torch.empty(M, K, device=dev)
+        nv.call("btvae_linear_dgrad", P(d), P(last.lin.weight), None, P(g), K, M, N, K)
+        svs = tape.heads[name]
+        for i in range(len(units) - 2, -1, -1):
+            first = i == 0
+            g = _unit_backward(units[i], svs[i], g, g_trunk if first else None, True, accumulate)
+        g_trunk = g
+    g = g_trunk
+    for i in range(len(plan.trunk) - 1, -1, -1):
+        g = _unit_backward(plan.trunk[i], tape.trunk[i], g, None, need_input_grad or i > 0, accumulate)
+    return g
+
+
+# -------------------------------------------------------------------------------------------------
+# dictionary-Gaussian likelihood (covariance GEMM + per-row inversion kernel + gradient GEMMs)
+# -------------------------------------------------------------------------------------------------
+class DictTables:
+    """Column-normalised dictionary and its packed outer-product table for one value of ``SigmaMapper``
+    (src/submodels.py:151-152,176-179)."""
+
+    def __init__(self, U: torch.Tensor, marginal_std_lim: float):
+        D, V = U.shape
+        dev = U.device
+        self.D, self.V, self.NP = D, V, D * (D + 1) // 2
+        self.Uhat = torch.empty(D, V, device=dev)
+        self.norms = torch.empty(V, device=dev)
+        self.UU = torch.empty(self.NP, V, device=dev)
+        self.diag = torch.empty(self.NP, device=dev)
+        nv.call("btvae_dict_prepare", P(U), P(self.Uhat), P(self.norms), P(self.UU), P(self.diag), D, V, float(marginal_std_lim))
+
+
+def dict_covariance_packed(tab: DictTables, sigma_sq: torch.Tensor) -> torch.Tensor:
+    rows = sigma_sq.shape[0]
+    Sp = torch.empty(rows, tab.NP, device=sigma_sq.device)
+    nv.call("btvae_matmul_nt_bias", P(sigma_sq), tab.V, P(tab.UU), tab.V, P(tab.diag), P(Sp), tab.NP, rows, tab.NP, tab.V)
+    return Sp
+
+
+def dict_loglik_fwd(tab: DictTables, x: torch.Tensor, mu: torch.Tensor, sigma_sq: torch.Tensor) -> torch.Tensor:
+    """log N(x[row % B]; mu[row], Sigma[row]) for every row (src/submodels.py:169-171)."""
+    rows, B = mu.shape[0], x.shape[0]
+    Sp = dict_covariance_packed(tab, sigma_sq)
+    logp = torch.empty(rows, device=mu.device)
+    nv.call("btvae_mvn_rows_fwd", P(Sp), P(mu), P(x), P(logp), rows, B, tab.D)
+    return logp
+
+
+def dict_loglik_fwd_bwd(tab: DictTables, x, mu, sigma, sigma_sq, dfac_mu, dfac_sigma, g_const: float, dU: torch.Tensor, accumulate=False,
+                        g_rows: Optional[torch.Tensor] = None):
+    """Log-likelihood rows plus gradients wrt the raw decoder head outputs and the dictionary, for an
+    upstream gradient ``g`` per row (constant, or ``g_rows``)."""
+    rows, B = mu.shape[0], x.shape[0]
+    dev = mu.device
+    Sp = dict_covariance_packed(tab, sigma_sq)
+    logp = torch.empty(rows, device=dev)
+    dmu = torch.empty(rows, tab.D, device=dev)
+    Pg = torch.empty(rows, tab.NP, device=dev)
+    nv.call("btvae_mvn_rows_fwd_bwd", P(Sp), P(mu), P(x), P(dfac_mu), P(g_rows), float(g_const), P(logp), P(dmu), P(Pg), rows, B, tab.D)
+    del Sp
+    dsig = torch.empty(rows, tab.V, device=dev)
+    nv.call("btvae_matmul_nn_mul", P(Pg), tab.NP, P(tab.UU), tab.V, P(sigma), P(dfac_sigma), tab.V, P(dsig), tab.V, rows, tab.V, tab.NP)
+    ws = WS.get("wgrad", WGRAD_WS_FLOATS, dev)
+    M1 = torch.empty(tab.NP, tab.V, device=dev)
+    nv.call("btvae_matmul_tn", P(Pg), tab.NP, P(sigma_sq), tab.V, P(M1), P(ws), ws.numel(), tab.NP, tab.V, rows, 0, 3)
+    nv.call("btvae_dict_grad", P(M1), P(tab.Uhat), P(tab.norms), P(dU), tab.D, tab.V, int(accumulate))
+    return logp, dmu, dsig
+
+
+def diag_loglik(x, mu, sigma, dfac_mu=None, dfac_sigma=None, g_const: float = 0.0, g_rows=None):
+    rows, D = mu.shape
+    B = x.shape[0]
+    logp = torch.empty(rows, device=mu.device)
+    if dfac_mu is None:
+        nv.call("btvae_diag_gauss_loglik", P(x), P(mu), P(sigma), P(logp), None, None, None, None, None, 0.0, rows, B, D)
+        return logp, None, None
+    dm, ds = torch.empty_like(mu), torch.empty_like(sigma)
+    nv.call("btvae_diag_gauss_loglik", P(x), P(mu), P(sigma), P(logp), P(dfac_mu), P(dfac_sigma), P(dm), P(ds), P(g_rows), float(g_const), rows, B, D)
+    return logp, dm, ds
+
+
+def reparam_kl(mu, sigma, eps, cond, S: int, three_d: bool, B: int, seed: int = 0, offset: int = 0):
+    """z‖c rows for the decoder and per-row KL.  2-D conditions: posterior rows R=B, S draws each
+    (src/vae_models.py:262-264).  3-D conditions ``cond[B,S,C]``: posterior rows R=S·B, one draw each
+    (src/vae_models.py:269-274).  eps None -> in-kernel Philox draws (returned)."""
+    R, L = mu.shape
+    dev = mu.device
+    C = cond.shape[-1] if cond is not None else 0
+    Sl = 1 if three_d else S
+    zc = torch.empty(Sl * R, L + C, device=dev)
+    kl = torch.empty(R, device=dev)
+    eps_out = None
+    if eps is None:
+        eps_out = torch.empty(Sl * R, L, device=dev)
+    if three_d:
+        cdiv, hi, lo = B, C, S * C
+    else:
+        cdiv, hi, lo = R, 0, C
+    nv.call("btvae_reparam_kl_fwd", P(mu), P(sigma), P(eps), P(eps_out), P(cond), P(zc), P(kl), R, Sl, L, C, cdiv, hi, lo, int(seed), int(offset))
+    return zc, kl, (eps if eps is not None else eps_out)
+
+
+def reparam_kl_bwd(dzc, eps, mu, sigma, dfac_mu, dfac_sigma, S: int, three_d: bool, C: int, kl_weight: float):
+    R, L = mu.shape
+    Sl = 1 if three_d else S
+    dm, ds = torch.empty_like(mu), torch.empty_like(sigma)
+    nv.call("btvae_reparam_kl_bwd", P(dzc), P(eps), P(mu), P(sigma), P(dfac_mu), P(dfac_sigma), P(dm), P(ds), R, Sl, L, C, float(kl_weight))
+    return dm, ds
+
+
+def elbo_scalars(logp: torch.Tensor, klrow: torch.Tensor, beta: float) -> torch.Tensor:
+    out = torch.empty(4, device=logp.device)
+    nv.call("btvae_elbo_scalars", P(logp), logp.numel(), P(klrow), klrow.numel(), float(beta), P(out))
+    return out
+
+
+class ClipAdam:
+    """State of the fused clip + Adam step over flat arenas (src/vae_models.py:103,323-324)."""
+
+    def __init__(self, n: int, device):
+        self.m = torch.zeros(n, device=device)
+        self.v = torch.zeros(n, device=device)
+        self.partials = torch.empty(512, dtype=torch.float64, device=device)
+        self.norm = torch.zeros(1, device=device)
+        self.step_count = 0
+
+    def step(self, params: torch.Tensor, grads: torch.Tensor, n: int, lr: float, betas, eps: float, weight_decay: float, max_norm: Optional[float]):
+        self.step_count += 1
+        nv.call("btvae_grad_sumsq", P(grads), n, P(self.partials))
+        nv.call("btvae_clip_adam_step", P(params), P(grads), P(self.m), P(self.v), n, P(self.partials),
+                float(max_norm) if max_norm is not None else -1.0, float(lr), float(betas[0]), float(betas[1]), float(eps),
+                float(weight_decay), self.step_count, P(self.norm))

@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the config0 ELBO training step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N>1, one rank per GPU)
+
+A step = one ``CVAE.train_core`` (forward, ELBO, backward, global-norm clip, Adam) on one resident batch of
+synthetic daily load profiles of the config0 shape (D=48, C=4, L=48, H=1000, V=100, S=16 MC samples,
+batch 4096 per GPU, fp32).  Inputs are generated on the device before the timed region.  Rank 0 prints one
+JSON line; ``value`` is whole-job samples/s.  Also reported: the roofline of the dominant kernel (the fp32 MFMA
+GEMM) from HIP-event timing on the launch stream inside the timed region, and a CPU baseline (the oracle
+restatement timed on the host cores, rank 0, N=1 only).
+"""
+import argparse
+import contextlib
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# effective config0 (reference: config_files/config0.json; batch 4096 per BASELINE.json configs[1])
+CONFIG0_MODEL = {
+    "latent_dim": 48,
+    "distribution_dict": {
+        "posterior": {"dist_type": "normal", "learn_sigma": True, "sigma_lim": 0.05, "total_max_std": 3.0, "mu_upper_lim": 5.0,
+                      "mu_lower_lim": -5.0, "num_neurons": 1000, "num_hidden_layers": 2, "dropout": False, "dropout_rate": 0.2,
+                      "batch_normalization": True, "resnet": False},
+        "likelihood": {"dist_type": "dict-gauss", "vocab_size": 100, "learn_sigma": True, "sigma_lim": 1e-4, "marginal_std_lim": 0.1,
+                       "total_max_std": 6.0, "mu_upper_lim": 5.0, "mu_lower_lim": -3, "num_neurons": 1000, "num_hidden_layers": 2,
+                       "dropout": False, "dropout_rate": 0.2, "batch_normalization": True, "resnet": False}}}
+CONFIG0_TRAIN = {"lr": 1e-3, "beta": 1.0, "num_mc_samples": 16, "weight_decay": 1e-5, "gradient_clipping": True,
+                 "gradient_clipping_kwargs": {"max_norm": 1.0}}
+D, C, SEED = 48, 4, 2112
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X fp32 matrix peak (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD)
+
+
+class Cdim:
+    def __init__(self, c):
+        self.cond_dim = c
+
+
+def synth_batch(rng, B):
+    """Synthetic profiles and calendar conditions of the config0 shape: x ~ clamp(N(1,1),-3,5) with 10 % of
+    entries at the zero id -3; months U{1..12}, weekdays U{0..6} circularly encoded as (cos.., sin..)."""
+    x = np.clip(rng.normal(1.0, 1.0, size=(B, D)), -3, 5)
+    x[rng.random((B, D)) < 0.1] = -3.0
+    months = rng.integers(1, 13, size=(B, 1)); weekdays = rng.integers(0, 7, size=(B, 1))
+    am = (months - 1) / 12 * 2 * np.pi; aw = weekdays / 7 * 2 * np.pi
+    c = np.concatenate([np.cos(am), np.sin(am), np.cos(aw), np.sin(aw)], axis=1)
+    return x.astype(np.float32), c.astype(np.float32)
+
+
+def flops_per_sample(S):
+    """Algorithmic FLOPs of one training sample: encoder 5,148,000 MAC + S x decoder 5,200,000 MAC forward,
+    x3 for forward + dgrad + wgrad, x2 FLOP/MAC (dictionary-Gaussian covariance GEMMs not counted)."""
+    return (5_148_000 + S * 5_200_000) * 2 * 3
+
+
+def cpu_baseline(B=1024, S=16, steps=2):
+    """The CPU oracle's train step (same algorithm as the reference's CPU path) on the host cores."""
+    from oracle import refimpl as R
+    cores = os.cpu_count() or 1
+    threads = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    torch.set_num_threads(threads)
+    spec = R.model_spec(D, C, CONFIG0_MODEL)
+    sd = R.init_state(spec, SEED)
+    st = R.AdamState()
+    rng = np.random.default_rng(SEED)
+    g = torch.Generator().manual_seed(SEED)
+    ts = []
+    for i in range(steps + 1):
+        x, c = synth_batch(rng, B)
+        eps = torch.randn(S, B, spec.latent_dim, generator=g)
+        t0 = time.perf_counter()
+        R.train_step(sd, spec, st, torch.from_numpy(x), torch.from_numpy(c), eps, lr=1e-3, weight_decay=1e-5, beta=1.0, max_norm=1.0)
+        ts.append(time.perf_counter() - t0)
+    dt = sum(ts[1:]) / steps
+    return {"value": B / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} train steps of B={B}, S={S} (config0 model) after 1 warm-up step, {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from behavio_temporal_vae_amd import _native as nv
+    from behavio_temporal_vae_amd.vae_models import CVAE
+
+    torch.manual_seed(SEED)
+    with contextlib.redirect_stdout(sys.stderr):   # the constructors print like the reference's; keep stdout for the JSON line
+        model = CVAE(input_dim=D, conditioner=Cdim(C), **CONFIG0_MODEL)
+    model = model.to(dev).train()
+    model.train_kwargs = dict(CONFIG0_TRAIN)
+    if world > 1:
+        model.enable_data_parallel()
+    optim = model.get_optimizer(lr=CONFIG0_TRAIN["lr"], weight_decay=CONFIG0_TRAIN["weight_decay"])
+    B, S = args.batch, CONFIG0_TRAIN["num_mc_samples"]
+    rng = np.random.default_rng(SEED + rank)
+    pool = []
+    for _ in range(4):
+        x, c = synth_batch(rng, B)
+        pool.append((torch.from_numpy(x).to(dev), torch.from_numpy(c).to(dev)))
+    torch.manual_seed(SEED + rank)
+
+    def step(i):
+        x, c = pool[i % len(pool)]
+        return model.train_core((x, c), optim)
+
+    for i in range(args.warmup):
+        loss = step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    nv.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = nv.prof_collect()
+    nv.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    last = {k: float(v.item()) for k, v in loss.items()}
+    if not all(math.isfinite(v) for v in last.values()):
+        raise SystemExit(f"non-finite loss terms: {last}")
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        gemm_ms = sum(prof[k][0] for k in ("gemm_fwd", "gemm_dgrad", "gemm_wgrad"))
+        gemm_fl = sum(prof[k][1] for k in ("gemm_fwd", "gemm_dgrad", "gemm_wgrad"))
+        fwd_ms, fwd_fl, _, fwd_n = prof["gemm_fwd"]
+        achieved = fwd_fl / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
+        kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[3] / args.steps,
+                       "tflops": (v[1] / (v[0] * 1e-3) / 1e12 if v[0] > 0 and v[1] > 0 else None),
+                       "gbps": (v[2] / (v[0] * 1e-3) / 1e9 if v[0] > 0 and v[2] > 0 else None)} for k, v in prof.items()}
+        out = {
+            "metric": "ELBO train samples/sec", "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config0.json training step, fused ELBO fwd/bwd + clip + Adam, fp32 MFMA", "global_batch": world * B,
+                       "per_gpu_batch": B, "num_mc_samples": S, "input_dim": D, "cond_dim": C, "latent_dim": 48, "hidden": 1000,
+                       "vocab": 100, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_mfma<k-contig,k-contig> (Linear forward family)", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "avg_launch_ms": fwd_ms / max(fwd_n, 1), "launches": fwd_n, "traffic": None,
+                         "all_gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None,
+                         "step_model_tflops": flops_per_sample(S) * B / (ms_step * 1e-3) / 1e12},
+            "kernels": kernels,
+            "last_loss": last,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+/* C-ABI of libbtvae_hip.so: gfx950 (MI355X) kernels for the conditional-VAE training and Monte-Carlo
+ * scoring path of kabolat/behavio-temporal-vae.
+ *
+ * The reference is pure Python/PyTorch and has no FFI of its own; each entry point below names the
+ * reference op sequence (file:line under the reference root) it replaces.  All pointers are DEVICE
+ * pointers to contiguous row-major fp32 arrays unless stated; `stream` is a hipStream_t.  Every function
+ * returns 0 on success, non-zero on failure with the reason in btvae_last_error().  Nothing here
+ * allocates or frees device memory or synchronises the device.
+ */
+#ifndef BTVAE_HIP_H
+#define BTVAE_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library state ---- */
+const char* btvae_last_error(void);
+int btvae_version(void);
+/* Select `device` and verify it is gfx950.  Call once per device before anything else. */
+int btvae_init(int device);
+/* Event timing per kernel family (0 gemm_fwd, 1 gemm_dgrad, 2 gemm_wgrad, 3 gemm_mvn, 4 bn, 5 mvn_rows,
+ * 6 reduce, 7 optim); collect after a device synchronisation into arrays of 8. */
+int btvae_prof_enable(int on);
+int btvae_prof_collect(double* ms, double* flops, double* bytes, long long* launches, int n);
+
+/* ---- Linear layers on MFMA (src/submodels.py:15-17 Linear+ReLU, :20-21 BatchNorm1d, :28-35 NNBlock.forward) ---- */
+/* Y[M,N] = relu(X[M,K] W[N,K]^T + b); stat_partials[ceil(M/128)][2][N] = per-row-tile column (mean, M2). */
+int btvae_linear_relu_stats_fwd(const float* X, int ldx, const float* W, const float* b, float* Y,
+                                float* stat_partials, int M, int K, int N, void* stream);
+/* Eval mode: Out = relu(X W^T + b) * scale + shift (+ R); scale/shift/R may be NULL. */
+int btvae_linear_relu_affine_fwd(const float* X, int ldx, const float* W, const float* b, const float* scale,
+                                 const float* shift, const float* R, float* Out, int M, int K, int N, void* stream);
+/* Head output Linear + non-linearity (src/submodels.py:102-104,156-157): act 0 clamp(raw,lo,hi),
+ * 1 clamp(softplus(raw, threshold 5),lo,hi) (src/utils.py:10), 2 clamp(relu(raw),lo,hi).
+ * Dfac = d Out / d raw and Sq = Out^2 are optional outputs (NULL to skip). */
+int btvae_linear_head_fwd(const float* X, int ldx, const float* W, const float* b, int act, float lo, float hi,
+                          float* Out, float* Dfac, float* Sq, int M, int K, int N, void* stream);
+/* dX[M,K] = dY[M,N] W[N,K] (+ R[M,K], same leading dimension lddx).  Replaces autograd's Linear dgrad
+ * (src/vae_models.py:322). */
+int btvae_linear_dgrad(const float* dY, const float* W, const float* R, float* dX, int lddx, int M, int N, int K, void* stream);
+/* dW[N,K] (+)= dY[M,N]^T X[M,K]; ws = split-reduction workspace of ws_floats floats (>= N*K to split). */
+int btvae_linear_wgrad(const float* dY, const float* X, int ldx, float* dW, float* ws, long long ws_floats,
+                       int M, int N, int K, int accumulate, void* stream);
+/* C[M,N] (+)= A^T B with A stored [K][M], B stored [K][N]. prof_kind: timing family to book under. */
+int btvae_matmul_tn(const float* A, int lda, const float* B, int ldb, float* C, float* ws, long long ws_floats,
+                    int M, int N, int K, int accumulate, int prof_kind, void* stream);
+/* C[M,N] = A[M,K] B[N,K]^T + bias[N]   (covariance build, src/submodels.py:176-179). */
+int btvae_matmul_nt_bias(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc,
+                         int M, int N, int K, void* stream);
+/* C[M,N] = A[M,K] B[N,K]^T + R[M,N]    (correlated sampling mu + Uhat (eps*sigma), src/submodels.py:160-164). */
+int btvae_matmul_nt_add(const float* A, int lda, const float* B, int ldb, const float* R, int ldr, float* C, int ldc,
+                        int M, int N, int K, void* stream);
+/* C[M,N] = (A[M,K] B[K,N]) * E1[M,N] * E2[M,N]. */
+int btvae_matmul_nn_mul(const float* A, int lda, const float* B, int ldb, const float* E1, const float* E2, int lde,
+                        float* C, int ldc, int M, int N, int K, void* stream);
+
+/* ---- BatchNorm1d (torch.nn.BatchNorm1d as used at src/submodels.py:20-21,50) ---- */
+int btvae_strip_chunks(int M);
+/* Merge the GEMM's per-tile partials: mean, invstd = 1/sqrt(biased var + eps); running buffers (may both be
+ * NULL) move with `momentum` using the unbiased variance. */
+int btvae_bn_stats_finalize(const float* partials, int ntiles, int M, int N, float* mean, float* invstd,
+                            float* running_mean, float* running_var, float momentum, float eps, void* stream);
+/* Eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale. */
+int btvae_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, float* scale, float* shift, int N, void* stream);
+/* Out = (Y-mean)*invstd*gamma + beta (+ R): normalisation and the residual add of src/submodels.py:32. */
+int btvae_bn_apply_fwd(const float* Y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                       const float* R, float* Out, int M, int N, void* stream);
+/* Backward of ReLU -> BatchNorm(train): from G = dL/dOut and the saved Y (post-ReLU) produce dgamma, dbeta,
+ * dbias (column sums of dPre) and dPre = dL/d(Linear output).  scratch: btvae_bn_relu_bwd_scratch(M,N) floats. */
+long long btvae_bn_relu_bwd_scratch(int M, int N);
+int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mean, const float* invstd, const float* gamma,
+                      float* dgamma, float* dbeta, float* dbias, float* dPre, float* scratch, int M, int N,
+                      int accumulate, void* stream);
+/* out[N] (+)= column sums of G[M,N]; scratch: btvae_strip_chunks(M)*N floats. */
+int btvae_colsum(const float* G, float* out, float* scratch, int M, int N, int accumulate, void* stream);
+
+/* ---- reparameterisation, KL, likelihoods ---- */
+/* z = mu + sigma*eps (src/submodels.py:108-109) written next to the broadcast condition as decoder input rows
+ * zc[S*R, L+C] (src/vae_models.py:264,274), and klrow[R] = sum_l KL(N(mu,sigma)||N(0,1)) (src/utils.py:29-33,
+ * src/vae_models.py:66-68).  Posterior row r, draw s <-> row s*R+r.  Condition of row r starts at
+ * cond + (r/cdiv)*cs_hi + (r%cdiv)*cs_lo.  eps NULL: Philox(seed, offset) draws, stored to eps_out if given. */
+int btvae_reparam_kl_fwd(const float* mu, const float* sigma, const float* eps, float* eps_out, const float* cond,
+                         float* zc, float* klrow, int R, int S, int L, int C, int cdiv, int cs_hi, int cs_lo,
+                         unsigned long long seed, unsigned long long offset, void* stream);
+/* Gradients wrt the encoder's raw head outputs from dzc and the KL term (weight kl_weight = beta / R). */
+int btvae_reparam_kl_bwd(const float* dzc, const float* eps, const float* mu, const float* sigma, const float* dfac_mu,
+                         const float* dfac_sigma, float* draw_mu, float* draw_sigma, int R, int S, int L, int C,
+                         float kl_weight, void* stream);
+/* logp[row] = sum_d log N(x[row % B][d]; mu, sigma) (src/submodels.py:114-115, src/utils.py:21-23); optional
+ * gradients wrt raw head outputs scaled by g (g_rows[row] or g_const). */
+int btvae_diag_gauss_loglik(const float* x, const float* mu, const float* sigma, float* logp, const float* dfac_mu,
+                            const float* dfac_sigma, float* draw_mu, float* draw_sigma, const float* g_rows, float g_const,
+                            int rows, int B, int D, void* stream);
+/* Uhat = U/||U[:,v]|| (src/utils.py:18-19), UU[p][v] = Uhat[d,v]*Uhat[e,v] for packed p=d(d+1)/2+e, diag[p] = m^2
+ * on diagonal entries. D <= 64. */
+int btvae_dict_prepare(const float* U, float* Uhat, float* norms, float* UU, float* diag, int D, int V,
+                       float marginal_std_lim, void* stream);
+/* dU (+)= gradient of the dictionary from M1[p][v] = sum_rows Pg[row][p]*sigma^2[row][v]. */
+int btvae_dict_grad(const float* M1, const float* Uhat, const float* norms, float* dU, int D, int V, int accumulate, void* stream);
+/* log N(x[row % B]; mu[row], Sigma[row]) from packed covariances (MultivariateNormal.log_prob, src/submodels.py:169-171). */
+int btvae_mvn_rows_fwd(const float* Sp, const float* mu, const float* x, float* logp, int rows, int B, int D, void* stream);
+/* Same plus backward seeds: dmu_raw = g*Sigma^-1(x-mu)*dfac_mu, Pg = g*(alpha alpha^T - Sigma^-1) packed with
+ * off-diagonals doubled. */
+int btvae_mvn_rows_fwd_bwd(const float* Sp, const float* mu, const float* x, const float* dfac_mu, const float* g_rows,
+                           float g_const, float* logp, float* dmu_raw, float* Pg, int rows, int B, int D, void* stream);
+/* out4 = [loss, elbo, rll, kl] with rll = mean(logp), kl = mean(klrow), loss = -(rll - beta*kl) (src/vae_models.py:70-74). */
+int btvae_elbo_scalars(const float* logp, int nlog, const float* klrow, int nkl, float beta, float* out4, void* stream);
+/* Streaming K-sample importance-weighted logsumexp (src/testing_lib.py:10-14): fold kc more samples into the
+ * running (max, sum) per profile; finalize writes ll = logsumexp - log K. */
+int btvae_iw_lse_update(const float* rll, const float* eps, const float* mu, const float* sigma, float* m_run, float* s_run,
+                        int kc, int N, int L, int first, void* stream);
+int btvae_iw_lse_finalize(const float* m_run, const float* s_run, float* ll, int N, int K, void* stream);
+
+/* ---- optimiser (src/vae_models.py:103,323-324) ---- */
+int btvae_grad_sumsq(const float* g, long long n, double* partials512, void* stream);
+int btvae_clip_adam_step(float* p, const float* g, float* m, float* v, long long n, const double* partials512,
+                         float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         long long step, float* norm_out, void* stream);
+int btvae_scale(float* x, long long n, float a, void* stream);
+
+/* ---- conditional imputation (src/imputation_lib.py:16-57,92,230-231) ---- */
+int btvae_cond_mvn_sample(const float* Sp, const float* mu, const float* x, const float* eps, unsigned long long obs_mask,
+                          const int* un_pos, float* samples, float* cond_mean, float* cond_cov, int rows, int D, int U,
+                          void* stream);
+int btvae_masked_scatter(float* dst, const long long* idx, const float* src, long long n, void* stream);
+int btvae_lse_over_k(const float* logp, float* out, int K, int B, void* stream);
+int btvae_pack_lower(const float* full, float* packed, long long rows, int D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
