@@ -206,6 +206,8 @@ class VAE(torch.nn.Module):
         x = self._prep(x, "inputs")
         B = x.shape[0]
         train = self.training
+        if tape and not train:
+            raise RuntimeError("a training step needs the model in train mode (call model.train())")
         three_d = c is not None and c.ndim == 3
         if c is not None:
             c = self._prep(c, "conditions")
@@ -316,28 +318,22 @@ class VAE(torch.nn.Module):
     def enable_data_parallel(self, process_group=None):
         """Average gradients (and the reported loss terms) over the ranks of ``process_group`` (RCCL) in
         every ``train_core``.  Decoder gradients are reduced while the encoder backward still runs."""
-        import torch.distributed as dist
-        self._dp_group = process_group
-        self._dp_world = dist.get_world_size(process_group)
-        self._dp_handles = []
+        from .parallel import GradSync
+        self._dp_sync = GradSync(process_group)
+        self._dp_world = self._dp_sync.world
 
     def _grads_ready(self, which: str):
         if self._dp_world <= 1:
             return
-        import torch.distributed as dist
         n = self._grad_arena.numel()
-        span = self._grad_arena[self._enc_span:n] if which == "decoder" else self._grad_arena[:self._enc_span]
-        self._dp_handles.append(dist.all_reduce(span, op=dist.ReduceOp.SUM, group=self._dp_group, async_op=True))
+        self._dp_sync.launch(self._grad_arena[self._enc_span:n] if which == "decoder" else self._grad_arena[:self._enc_span])
 
     def _dp_finish(self, scalars: torch.Tensor):
         if self._dp_world <= 1:
             return scalars
-        import torch.distributed as dist
-        for h in self._dp_handles:
-            h.wait()
-        self._dp_handles = []
+        self._dp_sync.finish()
         nv.call("btvae_scale", nv.ptr(self._grad_arena), self._grad_arena.numel(), 1.0 / self._dp_world)
-        dist.all_reduce(scalars, op=dist.ReduceOp.SUM, group=self._dp_group)
+        self._dp_sync.sum_(scalars)
         nv.call("btvae_scale", nv.ptr(scalars), 4, 1.0 / self._dp_world)
         return scalars
 
@@ -401,12 +397,16 @@ class VAE(torch.nn.Module):
         (reference: src/vae_models.py:108-116)."""
         if save_path is None:
             save_path = self.log_dir
+        was_training = self.training
         self.eval()
         self.to("cpu")
         self._prior_to("cpu")
         torch.save(self.state_dict(), os.path.join(save_path, model_name + ".pt"))
         self.to(device)
         self._prior_to(self.train_kwargs.get("device", device))
+        # The reference leaves the model in eval mode here, so its fit() trains with frozen BatchNorm statistics
+        # from a checkpoint until the next validation; that is treated as a defect and not reproduced.
+        self.train(was_training)
 
     def load(self, load_path=None, model_name="trained_model"):
         if load_path is None:
