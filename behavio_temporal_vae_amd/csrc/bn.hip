@@ -11,21 +11,38 @@ namespace {
 constexpr int STRIP_COLS = 256;   // columns per workgroup: 64 lanes x float4
 
 // ---- train-mode statistics: merge the per-row-tile (mean, M2) partials of the GEMM epilogue ----
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ partials, int ntiles, int tile_rows, int M, int N,
-                                         float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                         float* __restrict__ running_mean, float* __restrict__ running_var,
-                                         float momentum, float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partials, int ntiles, int tile_rows, int M, int N,
+                                                                float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                                float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                float momentum, float eps) {
+    // 32 columns x 8 tile-groups per workgroup: each thread Chan-merges every 8th tile in fp64, the 8 partial
+    // triples of a column are merged through LDS.
+    __shared__ double sh[3][8][32];
+    const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int t = 0; t < ntiles; ++t) {
-        const double nb = (double)min(tile_rows, M - t * tile_rows);
-        const double mb = partials[((size_t)t * 2 + 0) * N + c];
-        const double qb = partials[((size_t)t * 2 + 1) * N + c];
-        const double tot = n + nb, d = mb - mean;
-        m2 += qb + d * d * (n * nb / tot);
-        mean += d * (nb / tot);
-        n = tot;
+    if (c < N) {
+        for (int t = part; t < ntiles; t += 8) {
+            const double nb = (double)min(tile_rows, M - t * tile_rows);
+            const double mb = partials[((size_t)t * 2 + 0) * N + c];
+            const double qb = partials[((size_t)t * 2 + 1) * N + c];
+            const double tot = n + nb, d = mb - mean;
+            m2 += qb + d * d * (n * nb / tot);
+            mean += d * (nb / tot);
+            n = tot;
+        }
+    }
+    sh[0][part][cl] = n; sh[1][part][cl] = mean; sh[2][part][cl] = m2;
+    __syncthreads();
+    if (part != 0 || c >= N) return;
+    for (int q = 1; q < 8; ++q) {
+        const double nb = sh[0][q][cl], mb = sh[1][q][cl], qb = sh[2][q][cl];
+        if (nb > 0.0) {
+            const double tot = n + nb, d = mb - mean;
+            m2 += qb + d * d * (n * nb / tot);
+            mean += d * (nb / tot);
+            n = tot;
+        }
     }
     const double var_b = m2 / n;
     mean_out[c] = (float)mean;
@@ -122,16 +139,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
-// merge [nchunks][nvec][N] partial column sums in fp64; out_k (+)= sum
-__global__ void colsum_finalize_kernel(const float* __restrict__ partials, int nchunks, int nvec, int N,
-                                       float* out0, float* out1, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+// merge [nchunks][nvec][N] partial column sums in fp64 (32 columns x 8 chunk-groups per workgroup);
+// raw_k (if given) = sum, out_k (if given) (+)= sum
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partials, int nchunks, int nvec, int N,
+                                                              float* out0, float* out1, float* raw0, float* raw1, int accumulate) {
+    __shared__ double sh[8][32];
+    const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     for (int k = 0; k < nvec; ++k) {
         double s = 0.0;
-        for (int t = 0; t < nchunks; ++t) s += partials[((size_t)t * nvec + k) * N + c];
-        float* o = k == 0 ? out0 : out1;
-        if (o) o[c] = accumulate ? o[c] + (float)s : (float)s;
+        if (c < N) for (int t = part; t < nchunks; t += 8) s += partials[((size_t)t * nvec + k) * N + c];
+        sh[part][cl] = s;
+        __syncthreads();
+        if (part == 0 && c < N) {
+            for (int q = 1; q < 8; ++q) s += sh[q][cl];
+            float* o = k == 0 ? out0 : out1;
+            float* r = k == 0 ? raw0 : raw1;
+            if (r) r[c] = (float)s;
+            if (o) o[c] = accumulate ? o[c] + (float)s : (float)s;
+        }
+        __syncthreads();
     }
 }
 
@@ -239,7 +266,7 @@ BTVAE_API int btvae_bn_stats_finalize(const float* partials, int ntiles, int M, 
     BTVAE_REQUIRE(ntiles == (M + 127) / 128, "bn_stats_finalize: ntiles %d does not match M %d", ntiles, M);
     BTVAE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize: pass both running buffers or neither");
     ProfScope ps(PK_BN, (hipStream_t)stream, 0, 8.0 * ntiles * N);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, partials, ntiles, 128, M, N,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, ntiles, 128, M, N,
                        mean, invstd, running_mean, running_var, momentum, eps);
     return check_launch("bn_stats_finalize");
 }
@@ -281,13 +308,10 @@ BTVAE_API int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mea
     // k=0 -> sum g (dbeta), k=1 -> sum g*xhat (dgamma); current-batch values go to the tail of the scratch
     float* cur_dbeta = scratch + (size_t)3 * chunks * N;
     float* cur_dgamma = cur_dbeta + N;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, s, p2, chunks, 2, N, cur_dbeta, cur_dgamma, 0);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, p2, chunks, 2, N, dbeta, dgamma, cur_dbeta, cur_dgamma, accumulate);
     if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, dPre, p1, M, N, rpc);
     else    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, dPre, p1, M, N, rpc);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, s, p1, chunks, 1, N, dbias, (float*)nullptr, accumulate);
-    // publish dgamma / dbeta
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, s, cur_dbeta, 1, 1, N, dbeta, (float*)nullptr, accumulate);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, s, cur_dgamma, 1, 1, N, dgamma, (float*)nullptr, accumulate);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, p1, chunks, 1, N, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
     return check_launch("bn_relu_bwd");
 }
 
@@ -304,6 +328,6 @@ BTVAE_API int btvae_colsum(const float* G, float* out, float* scratch, int M, in
         hipLaunchKernelGGL((colsum_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, scratch, M, N, rpc);
     else
         hipLaunchKernelGGL((colsum_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, scratch, M, N, rpc);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, s, scratch, chunks, 1, N, out, (float*)nullptr, accumulate);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, scratch, chunks, 1, N, out, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
     return check_launch("colsum");
 }

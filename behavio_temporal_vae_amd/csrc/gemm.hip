@@ -128,9 +128,14 @@ __device__ __forceinline__ float4 frag(const float* S, int rc, int g, int lh) {
 
 __device__ __forceinline__ float softplus5(float x) { return x > 5.f ? x : log1pf(expf(x)); }
 
+#ifndef BTVAE_GEMM_NBUF
+#define BTVAE_GEMM_NBUF 2     // LDS buffers per operand: 1 = 36 KB per workgroup (3 workgroups per CU), 2 = 72 KB (2 per CU)
+#endif
+constexpr int NBUF = BTVAE_GEMM_NBUF;
+
 template <int AL, int BL, int EPI, bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2][2][TILE_FLOATS];
+__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_mfma(const GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[NBUF][2][TILE_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs p) {
     __syncthreads();
 
     for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
+        const int cur = NBUF == 2 ? (t & 1) : 0;
         const bool more = t + 1 < nk;
         const int k0 = kbeg + t * BK;
         if (more) {
@@ -178,30 +183,48 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(const GemmArgs p) {
         const float* Bs = smem[cur][1];
         const int krem = kend - k0;
         const int ngroups = krem >= BK ? 4 : (krem + 7) >> 3;
+        // fragments of k-group g+1 are fetched from LDS while the 16 MFMAs of group g issue
+        float4 a[2][2], b[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) a[0][rb] = frag<AL>(As, wr * 64 + rb * 32 + li, 0, lh);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) b[0][cb] = frag<BL>(Bs, wc * 64 + cb * 32 + li, 0, lh);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g < ngroups) {
-                float4 a[2], b[2];
+                if (g + 1 < 4 && g + 1 < ngroups) {
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) a[rb] = frag<AL>(As, wr * 64 + rb * 32 + li, g, lh);
+                    for (int rb = 0; rb < 2; ++rb) a[(g + 1) & 1][rb] = frag<AL>(As, wr * 64 + rb * 32 + li, g + 1, lh);
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) b[cb] = frag<BL>(Bs, wc * 64 + cb * 32 + li, g, lh);
+                    for (int cb = 0; cb < 2; ++cb) b[(g + 1) & 1][cb] = frag<BL>(Bs, wc * 64 + cb * 32 + li, g + 1, lh);
+                }
+                const float4 (&ag)[2] = a[g & 1];
+                const float4 (&bg)[2] = b[g & 1];
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb) {
-                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb].x, b[cb].x, acc[rb][cb], 0, 0, 0);
-                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb].y, b[cb].y, acc[rb][cb], 0, 0, 0);
-                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb].z, b[cb].z, acc[rb][cb], 0, 0, 0);
-                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb].w, b[cb].w, acc[rb][cb], 0, 0, 0);
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[rb].x, bg[cb].x, acc[rb][cb], 0, 0, 0);
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[rb].y, bg[cb].y, acc[rb][cb], 0, 0, 0);
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[rb].z, bg[cb].z, acc[rb][cb], 0, 0, 0);
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[rb].w, bg[cb].w, acc[rb][cb], 0, 0, 0);
                     }
             }
         }
-        if (more) {
-            r2s<AL>(smem[cur ^ 1][0], tid, sa);
-            r2s<BL>(smem[cur ^ 1][1], tid, sb);
+        if (NBUF == 2) {
+            if (more) {
+                r2s<AL>(smem[cur ^ 1][0], tid, sa);
+                r2s<BL>(smem[cur ^ 1][1], tid, sb);
+            }
+            __syncthreads();
+        } else {
+            __syncthreads();            // every wave has read this tile
+            if (more) {
+                r2s<AL>(smem[0][0], tid, sa);
+                r2s<BL>(smem[0][1], tid, sb);
+                __syncthreads();        // next tile visible
+            }
         }
-        __syncthreads();
     }
 
     // ---- epilogue: accumulator element r of tile (rb,cb) is row (r&3)+8(r>>2)+4*lh, column li ----

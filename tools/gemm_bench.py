@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the GEMM family at the config0 decoder shapes (M=65536, N=K=1000): prints TFLOP/s per
+layout.  Used on its own and under ``rocprofv3 --pmc`` to read MFMA-busy / wait counters."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from behavio_temporal_vae_amd import _native as nv  # noqa: E402
+
+P = nv.ptr
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    dev = torch.device("cuda:0")
+    nv.ensure_device(dev)
+    M, N, K = 65536, 1000, 1000
+    g = torch.Generator(device=dev).manual_seed(0)
+    X = torch.randn(M, K, device=dev, generator=g)
+    W = torch.randn(N, K, device=dev, generator=g) * 0.03
+    b = torch.randn(N, device=dev, generator=g)
+    Y = torch.empty(M, N, device=dev)
+    part = torch.empty((M + 127) // 128, 2, N, device=dev)
+    dX = torch.empty(M, K, device=dev)
+    dW = torch.empty(N, K, device=dev)
+    ws = torch.empty(32 * 1024 * 1024, device=dev)
+    ops = {
+        "fwd": lambda: nv.call("btvae_linear_relu_stats_fwd", P(X), K, P(W), P(b), P(Y), P(part), M, K, N),
+        "dgrad": lambda: nv.call("btvae_linear_dgrad", P(Y), P(W), None, P(dX), K, M, N, K),
+        "wgrad": lambda: nv.call("btvae_linear_wgrad", P(Y), P(X), K, P(dW), P(ws), ws.numel(), M, N, K, 0),
+    }
+    for name, fn in ops.items():
+        if which not in ("all", name):
+            continue
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        print(f"{name}: {dt*1e3:.3f} ms  {2.0*M*N*K/dt/1e12:.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
