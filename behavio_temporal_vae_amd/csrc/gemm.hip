@@ -171,60 +171,67 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_mfma(const Ge
     }
     __syncthreads();
 
-    for (int t = 0; t < nk; ++t) {
+    // Steady state: tiles 0 .. nk-2 are always full (only the last k-tile of a chunk can be short), so their
+    // body is straight-line: prefetch tile t+1 to registers, 4 k-groups of 16 MFMAs with the fragments of
+    // group g+1 fetched from LDS while group g issues, then publish tile t+1.  The last tile is peeled.
+    auto mma_group = [&](const float4 (&ag)[2], const float4 (&bg)[2]) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[rb].x, bg[cb].x, acc[rb][cb], 0, 0, 0);
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[rb].y, bg[cb].y, acc[rb][cb], 0, 0, 0);
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[rb].z, bg[cb].z, acc[rb][cb], 0, 0, 0);
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[rb].w, bg[cb].w, acc[rb][cb], 0, 0, 0);
+            }
+    };
+    auto load_group = [&](const float* As, const float* Bs, int g, float4 (&ag)[2], float4 (&bg)[2]) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) ag[rb] = frag<AL>(As, wr * 64 + rb * 32 + li, g, lh);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) bg[cb] = frag<BL>(Bs, wc * 64 + cb * 32 + li, g, lh);
+    };
+
+    int t = 0;
+    for (; t + 1 < nk; ++t) {
         const int cur = NBUF == 2 ? (t & 1) : 0;
-        const bool more = t + 1 < nk;
         const int k0 = kbeg + t * BK;
-        if (more) {
-            g2r<AL, VEC>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, sa);
-            g2r<BL, VEC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, sb);
-        }
+        g2r<AL, VEC>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, sa);
+        g2r<BL, VEC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, sb);
         const float* As = smem[cur][0];
         const float* Bs = smem[cur][1];
-        const int krem = kend - k0;
-        const int ngroups = krem >= BK ? 4 : (krem + 7) >> 3;
-        // fragments of k-group g+1 are fetched from LDS while the 16 MFMAs of group g issue
-        float4 a[2][2], b[2][2];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) a[0][rb] = frag<AL>(As, wr * 64 + rb * 32 + li, 0, lh);
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) b[0][cb] = frag<BL>(Bs, wc * 64 + cb * 32 + li, 0, lh);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g < ngroups) {
-                if (g + 1 < 4 && g + 1 < ngroups) {
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb) a[(g + 1) & 1][rb] = frag<AL>(As, wr * 64 + rb * 32 + li, g + 1, lh);
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) b[(g + 1) & 1][cb] = frag<BL>(Bs, wc * 64 + cb * 32 + li, g + 1, lh);
-                }
-                const float4 (&ag)[2] = a[g & 1];
-                const float4 (&bg)[2] = b[g & 1];
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) {
-                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[rb].x, bg[cb].x, acc[rb][cb], 0, 0, 0);
-                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[rb].y, bg[cb].y, acc[rb][cb], 0, 0, 0);
-                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[rb].z, bg[cb].z, acc[rb][cb], 0, 0, 0);
-                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[rb].w, bg[cb].w, acc[rb][cb], 0, 0, 0);
-                    }
-            }
-        }
+        float4 a0[2], b0[2], a1[2], b1[2];
+        load_group(As, Bs, 0, a0, b0);
+        load_group(As, Bs, 1, a1, b1);
+        mma_group(a0, b0);
+        load_group(As, Bs, 2, a0, b0);
+        mma_group(a1, b1);
+        load_group(As, Bs, 3, a1, b1);
+        mma_group(a0, b0);
+        mma_group(a1, b1);
         if (NBUF == 2) {
-            if (more) {
-                r2s<AL>(smem[cur ^ 1][0], tid, sa);
-                r2s<BL>(smem[cur ^ 1][1], tid, sb);
-            }
+            r2s<AL>(smem[cur ^ 1][0], tid, sa);
+            r2s<BL>(smem[cur ^ 1][1], tid, sb);
             __syncthreads();
         } else {
             __syncthreads();            // every wave has read this tile
-            if (more) {
-                r2s<AL>(smem[0][0], tid, sa);
-                r2s<BL>(smem[0][1], tid, sb);
-                __syncthreads();        // next tile visible
-            }
+            r2s<AL>(smem[0][0], tid, sa);
+            r2s<BL>(smem[0][1], tid, sb);
+            __syncthreads();            // next tile visible
         }
+    }
+    if (nk > 0) {                       // last tile: 1..4 k-groups
+        const int cur = NBUF == 2 ? (t & 1) : 0;
+        const float* As = smem[cur][0];
+        const float* Bs = smem[cur][1];
+        const int krem = kend - (kbeg + t * BK);
+        const int ngroups = krem >= BK ? 4 : (krem + 7) >> 3;
+        for (int g = 0; g < ngroups; ++g) {
+            float4 ag[2], bg[2];
+            load_group(As, Bs, g, ag, bg);
+            mma_group(ag, bg);
+        }
+        __syncthreads();
     }
 
     // ---- epilogue: accumulator element r of tile (rb,cb) is row (r&3)+8(r>>2)+4*lh, column li ----

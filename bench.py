@@ -86,6 +86,54 @@ def cpu_baseline(B=1024, S=16, steps=2):
             "sample": f"{steps} train steps of B={B}, S={S} (config0 model) after 1 warm-up step, {dt:.2f} s/step"}
 
 
+GIPUZKOA_MODEL = {
+    "latent_dim": 24,
+    "distribution_dict": {
+        "posterior": {"dist_type": "normal", "learn_sigma": True, "sigma_lim": 0.05, "average_max_std": 1.0, "mu_upper_lim": 5.0,
+                      "mu_lower_lim": -5.0, "num_neurons": 1000, "num_hidden_layers": 2, "dropout": True, "dropout_rate": 0.2,
+                      "batch_normalization": True, "resnet": False},
+        "likelihood": {"dist_type": "dict-gauss", "vocab_size": 100, "learn_sigma": True, "sigma_lim": 1e-6, "marginal_std_lim": 0.05,
+                       "average_max_std": 1.0, "mu_upper_lim": 5.0, "mu_lower_lim": -3, "num_neurons": 1000, "num_hidden_layers": 2,
+                       "dropout": True, "dropout_rate": 0.2, "batch_normalization": True, "resnet": False}}}
+
+
+def scoring_benchmark(dev, rank, world, n_profiles, K, chunk):
+    """K-sample importance-weighted log-likelihood of the config0_gipuzkoa-shaped model (D=24, L=24, C=4, H=1000,
+    V=100, eval mode): every rank scores its own ``n_profiles`` resident profiles (weak scaling), one reduce of
+    (sum ll, count) at the end.  Returns whole-job profiles/s."""
+    import torch.distributed as dist
+    from behavio_temporal_vae_amd import testing_lib
+    from behavio_temporal_vae_amd.parallel import reduce_loglik
+    from behavio_temporal_vae_amd.vae_models import CVAE
+    torch.manual_seed(SEED)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = CVAE(input_dim=24, conditioner=Cdim(C), **GIPUZKOA_MODEL)
+    model = model.to(dev).eval()
+    rng = np.random.default_rng(SEED + 100 + rank)
+    x = np.clip(rng.normal(1.0, 1.0, size=(n_profiles, 24)), -3, 5).astype(np.float32)
+    ang = rng.uniform(0, 2 * np.pi, size=(n_profiles, 2))
+    c = np.concatenate([np.cos(ang), np.sin(ang)], 1).astype(np.float32)
+    xd, cd = torch.from_numpy(x).to(dev), torch.from_numpy(c).to(dev)
+    testing_lib.iw_loglikelihood_device(model, xd[:256], cd[:256], 2 * chunk, chunk)     # warm-up
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ll, _, _ = testing_lib.iw_loglikelihood_device(model, xd, cd, K, chunk)
+    tot, cnt = reduce_loglik(float(ll.double().sum().item()), n_profiles, device=dev)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    flops = (5_076_000 + K * 5_152_000) * 2.0 * cnt
+    return {"metric": "MC-scored profiles/sec at K=1000", "value": cnt / dt, "unit": "profiles/s", "K": K, "profiles": cnt,
+            "seconds": dt, "mean_loglik": tot / cnt, "model_tflops": flops / dt / 1e12,
+            "config": {"workload": "config0_gipuzkoa-shaped IW log-likelihood, eval mode", "input_dim": 24, "latent_dim": 24,
+                       "hidden": 1000, "vocab": 100, "mc_chunk": chunk, "per_gpu_profiles": n_profiles}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +141,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scoring-profiles", type=int, default=4096, help="per-GPU profiles of the K=1000 scoring leg (0 = skip)")
+    ap.add_argument("--scoring-k", type=int, default=1000)
+    ap.add_argument("--scoring-chunk", type=int, default=25, help="latent draws per decoder pass")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,6 +204,13 @@ def main():
     if not all(math.isfinite(v) for v in last.values()):
         raise SystemExit(f"non-finite loss terms: {last}")
 
+    scoring = None
+    if args.scoring_profiles > 0:
+        del pool
+        model.to("cpu")
+        torch.cuda.empty_cache()
+        scoring = scoring_benchmark(dev, rank, world, args.scoring_profiles, args.scoring_k, args.scoring_chunk)
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
@@ -178,6 +236,8 @@ def main():
             "kernels": kernels,
             "last_loss": last,
         }
+        if scoring is not None:
+            out["secondary"] = scoring
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
