@@ -18,10 +18,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
+#ifndef BTVAE_GEMM_BK
+#define BTVAE_GEMM_BK 16      // k-tile depth: 16 -> 40 KB of LDS per workgroup (3 workgroups per CU), 32 -> 72 KB (2 per CU)
+#endif
+constexpr int BM = 128, BN = 128, BK = BTVAE_GEMM_BK;
+constexpr int NQ = BK / 8;              // 16-byte staging loads per operand per thread per k-tile
+constexpr int NG = BK / 8;              // k-groups (8 k = 4 MFMA steps x 2 lane halves) per k-tile
 constexpr int LDK = BK + 4;             // row stride (floats) of a k-contiguous LDS tile: 16-B slots 9 apart -> conflict-free b128
 constexpr int LDM = 128 + 4;            // row stride of an m/n-contiguous LDS tile
-constexpr int TILE_FLOATS = 128 * LDK;  // 4608 >= 32 * LDM
+constexpr int TILE_FLOATS = (128 * LDK > BK * LDM) ? 128 * LDK : BK * LDM;
+constexpr int KC4 = BK / 4;             // 16-byte chunks per row of a k-contiguous tile
 
 enum { LAY_K = 0, LAY_M = 1 };
 enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_RELU_STATS = 2, EPI_RELU_AFFINE = 3, EPI_HEAD = 4, EPI_MUL = 5 };
@@ -48,14 +54,14 @@ struct GemmArgs {
 // 8 loads of a k-tile stay in flight behind the MFMAs of the current tile.
 template <int LAY>
 __device__ __forceinline__ void g2r_vec(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int kend,
-                                        int tid, float4 (&st)[4]) {
+                                        int tid, float4 (&st)[NQ]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int f = tid + 256 * q;
         bool ok;
         size_t off;
         if (LAY == LAY_K) {
-            const int gr = row0 + (f >> 3), gk = k0 + ((f & 7) << 2);
+            const int gr = row0 + f / KC4, gk = k0 + ((f % KC4) << 2);
             ok = gr < nrows && gk + 3 < kend;
             off = (size_t)gr * ld + gk;
         } else {
@@ -71,15 +77,15 @@ __device__ __forceinline__ void g2r_vec(const float* __restrict__ P, int ld, int
 
 template <int LAY, bool VEC>
 __device__ __forceinline__ void g2r(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int kend,
-                                    int tid, float4 (&st)[4]) {
+                                    int tid, float4 (&st)[NQ]) {
     if (VEC) { g2r_vec<LAY>(P, ld, row0, nrows, k0, kend, tid, st); return; }
     const int vec = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int f = tid + 256 * q;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (LAY == LAY_K) {
-            const int r = f >> 3, c = (f & 7) << 2;
+            const int r = f / KC4, c = (f % KC4) << 2;
             const int gr = row0 + r, gk = k0 + c;
             if (gr < nrows && gk < kend) {
                 const float* src = P + (size_t)gr * ld + gk;
@@ -110,11 +116,11 @@ __device__ __forceinline__ void g2r(const float* __restrict__ P, int ld, int row
 }
 
 template <int LAY>
-__device__ __forceinline__ void r2s(float* S, int tid, const float4 (&st)[4]) {
+__device__ __forceinline__ void r2s(float* S, int tid, const float4 (&st)[NQ]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int f = tid + 256 * q;
-        if (LAY == LAY_K) *reinterpret_cast<float4*>(S + (f >> 3) * LDK + ((f & 7) << 2)) = st[q];
+        if (LAY == LAY_K) *reinterpret_cast<float4*>(S + (f / KC4) * LDK + ((f % KC4) << 2)) = st[q];
         else              *reinterpret_cast<float4*>(S + (f >> 5) * LDM + ((f & 31) << 2)) = st[q];
     }
 }
@@ -134,7 +140,7 @@ __device__ __forceinline__ float softplus5(float x) { return x > 5.f ? x : log1p
 constexpr int NBUF = BTVAE_GEMM_NBUF;
 
 template <int AL, int BL, int EPI, bool VEC>
-__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_mfma(const GemmArgs p) {
+__global__ __launch_bounds__(256, (NBUF == 1 || BK == 16) ? 3 : 2) void gemm_f32_mfma(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[NBUF][2][TILE_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_mfma(const Ge
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 sa[4], sb[4];
+    float4 sa[NQ], sb[NQ];
     if (nk > 0) {
         g2r<AL, VEC>(p.A, p.lda, m0, p.M, kbeg, kend, tid, sa);
         g2r<BL, VEC>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, sb);
@@ -202,13 +208,13 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_mfma(const Ge
         const float* Bs = smem[cur][1];
         float4 a0[2], b0[2], a1[2], b1[2];
         load_group(As, Bs, 0, a0, b0);
-        load_group(As, Bs, 1, a1, b1);
-        mma_group(a0, b0);
-        load_group(As, Bs, 2, a0, b0);
-        mma_group(a1, b1);
-        load_group(As, Bs, 3, a1, b1);
-        mma_group(a0, b0);
-        mma_group(a1, b1);
+#pragma unroll
+        for (int g = 0; g < NG; g += 2) {
+            load_group(As, Bs, g + 1, a1, b1);
+            mma_group(a0, b0);
+            if (g + 2 < NG) load_group(As, Bs, g + 2, a0, b0);
+            mma_group(a1, b1);
+        }
         if (NBUF == 2) {
             r2s<AL>(smem[cur ^ 1][0], tid, sa);
             r2s<BL>(smem[cur ^ 1][1], tid, sb);
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gemm_f32_mfma(const Ge
         const float* As = smem[cur][0];
         const float* Bs = smem[cur][1];
         const int krem = kend - (kbeg + t * BK);
-        const int ngroups = krem >= BK ? 4 : (krem + 7) >> 3;
+        const int ngroups = krem >= BK ? NG : (krem + 7) >> 3;
         for (int g = 0; g < ngroups; ++g) {
             float4 ag[2], bg[2];
             load_group(As, Bs, g, ag, bg);
