@@ -33,8 +33,9 @@ _SIGS = {
     "btvae_matmul_nn_mul": [P, I, P, I, P, P, I, P, I, I, I, I, P],
     "btvae_bn_stats_finalize": [P, I, I, I, P, P, P, P, F, F, P],
     "btvae_bn_fold_eval": [P, P, P, P, F, P, P, I, P],
-    "btvae_bn_apply_fwd": [P, P, P, P, P, P, P, I, I, P],
-    "btvae_bn_relu_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "btvae_bn_apply_fwd": [P, P, P, P, P, P, P, F, P, I, I, P],
+    "btvae_bn_relu_bwd": [P, P, P, P, P, P, F, P, P, P, P, P, I, I, I, P],
+    "btvae_dropout_keep_mask": [P, LL, F, ULL, ULL, P],
     "btvae_colsum": [P, P, P, I, I, I, P],
     "btvae_reparam_kl_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, ULL, ULL, P],
     "btvae_reparam_kl_bwd": [P, P, P, P, P, P, P, P, I, I, I, I, F, P],

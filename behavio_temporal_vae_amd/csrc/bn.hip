@@ -68,6 +68,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ Y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ R,
+                                                           const unsigned char* __restrict__ keep, float keep_scale,
                                                            float* __restrict__ Out, int M, int N, int rows_per_chunk) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + lane) * VEC;
@@ -85,10 +86,16 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
         if (VEC == 4) {
             float4 y = *reinterpret_cast<const float4*>(Y + o);
             float4 v = make_float4(y.x * sc[0] + sh[0], y.y * sc[1] + sh[1], y.z * sc[2] + sh[2], y.w * sc[3] + sh[3]);
+            if (keep) {
+                const uchar4 k = *reinterpret_cast<const uchar4*>(keep + o);
+                v.x = k.x ? v.x * keep_scale : 0.f; v.y = k.y ? v.y * keep_scale : 0.f;
+                v.z = k.z ? v.z * keep_scale : 0.f; v.w = k.w ? v.w * keep_scale : 0.f;
+            }
             if (R) { const float4 q = *reinterpret_cast<const float4*>(R + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
             *reinterpret_cast<float4*>(Out + o) = v;
         } else {
             float v = Y[o] * sc[0] + sh[0];
+            if (keep) v = keep[o] ? v * keep_scale : 0.f;
             if (R) v += R[o];
             Out[o] = v;
         }
@@ -99,6 +106,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ G, const float* __restrict__ Y,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const unsigned char* __restrict__ keep, float keep_scale,
                                                             float* __restrict__ partials, int M, int N, int rows_per_chunk) {
     __shared__ float red[4][64][2 * VEC];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -113,14 +121,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         for (int r = r0 + w; r < r1; r += 4) {
             const size_t o = (size_t)r * N + col;
             if (VEC == 4) {
-                const float4 g = *reinterpret_cast<const float4*>(G + o);
+                float4 g = *reinterpret_cast<const float4*>(G + o);
                 const float4 y = *reinterpret_cast<const float4*>(Y + o);
+                if (keep) {
+                    const uchar4 k = *reinterpret_cast<const uchar4*>(keep + o);
+                    g.x = k.x ? g.x * keep_scale : 0.f; g.y = k.y ? g.y * keep_scale : 0.f;
+                    g.z = k.z ? g.z * keep_scale : 0.f; g.w = k.w ? g.w * keep_scale : 0.f;
+                }
                 s1[0] += g.x; s2[0] += g.x * ((y.x - mu[0]) * is[0]);
                 s1[1] += g.y; s2[1] += g.y * ((y.y - mu[1]) * is[1]);
                 s1[2] += g.z; s2[2] += g.z * ((y.z - mu[2]) * is[2]);
                 s1[3] += g.w; s2[3] += g.w * ((y.w - mu[3]) * is[3]);
             } else {
-                const float g = G[o], y = Y[o];
+                float g = G[o];
+                const float y = Y[o];
+                if (keep) g = keep[o] ? g * keep_scale : 0.f;
                 s1[0] += g; s2[0] += g * ((y - mu[0]) * is[0]);
             }
         }
@@ -167,7 +182,9 @@ template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ Y,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ dgamma,
-                                                           const float* __restrict__ dbeta, float* __restrict__ dPre,
+                                                           const float* __restrict__ dbeta,
+                                                           const unsigned char* __restrict__ keep, float keep_scale,
+                                                           float* __restrict__ dPre,
                                                            float* __restrict__ db_partials, int M, int N, int rows_per_chunk) {
     __shared__ float red[4][64][VEC];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -191,8 +208,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         for (int r = r0 + w; r < r1; r += 4) {
             const size_t o = (size_t)r * N + col;
             if (VEC == 4) {
-                const float4 g = *reinterpret_cast<const float4*>(G + o);
+                float4 g = *reinterpret_cast<const float4*>(G + o);
                 const float4 y = *reinterpret_cast<const float4*>(Y + o);
+                if (keep) {
+                    const uchar4 k = *reinterpret_cast<const uchar4*>(keep + o);
+                    g.x = k.x ? g.x * keep_scale : 0.f; g.y = k.y ? g.y * keep_scale : 0.f;
+                    g.z = k.z ? g.z * keep_scale : 0.f; g.w = k.w ? g.w * keep_scale : 0.f;
+                }
                 float4 d;
                 d.x = y.x > 0.f ? k0[0] * g.x - k1[0] - k2[0] * ((y.x - mu[0]) * is[0]) : 0.f;
                 d.y = y.y > 0.f ? k0[1] * g.y - k1[1] - k2[1] * ((y.y - mu[1]) * is[1]) : 0.f;
@@ -201,7 +223,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 *reinterpret_cast<float4*>(dPre + o) = d;
                 sb[0] += d.x; sb[1] += d.y; sb[2] += d.z; sb[3] += d.w;
             } else {
-                const float g = G[o], y = Y[o];
+                float g = G[o];
+                const float y = Y[o];
+                if (keep) g = keep[o] ? g * keep_scale : 0.f;
                 const float d = y > 0.f ? k0[0] * g - k1[0] - k2[0] * ((y - mu[0]) * is[0]) : 0.f;
                 dPre[o] = d;
                 sb[0] += d;
@@ -246,6 +270,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ G
     }
 }
 
+// Bernoulli(1-p) keep flags, one byte per element; four elements share one Philox counter
+__global__ __launch_bounds__(256) void dropout_keep_kernel(unsigned char* __restrict__ keep, long long n, float p,
+                                                           unsigned long long seed, unsigned long long offset) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i0 = q * 4;
+    if (i0 >= n) return;
+    const uint4 c = philox4x32(seed, offset, (unsigned long long)q);
+    const unsigned r[4] = {c.x, c.y, c.z, c.w};
+    unsigned char k[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k[j] = ((float)(r[j] >> 8) * 5.9604644775390625e-08f) >= p ? 1 : 0;   // uniform [0,1) from 24 bits
+    if (i0 + 4 <= n) *reinterpret_cast<uchar4*>(keep + i0) = make_uchar4(k[0], k[1], k[2], k[3]);
+    else for (int j = 0; i0 + j < n; ++j) keep[i0 + j] = k[j];
+}
+
 inline bool vec4_ok(int N, const void* a, const void* b, const void* c, const void* d) {
     auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return N % 4 == 0 && al(a) && al(b) && al(c) && al(d);
@@ -279,14 +318,15 @@ BTVAE_API int btvae_bn_fold_eval(const float* gamma, const float* beta, const fl
 }
 
 BTVAE_API int btvae_bn_apply_fwd(const float* Y, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                 const float* R, float* Out, int M, int N, void* stream) {
+                                 const float* R, const unsigned char* keep, float keep_scale, float* Out, int M, int N,
+                                 void* stream) {
     BTVAE_REQUIRE(Y && mean && invstd && gamma && beta && Out, "bn_apply_fwd: null pointer");
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
-    ProfScope ps(PK_BN, (hipStream_t)stream, 0, 4.0 * M * N * (R ? 3 : 2));
-    if (vec4_ok(N, Y, R, Out, nullptr))
-        hipLaunchKernelGGL((bn_apply_fwd_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, Out, M, N, rpc);
+    ProfScope ps(PK_BN, (hipStream_t)stream, 0, 4.0 * M * N * (R ? 3 : 2) + (keep ? 1.0 * M * N : 0.0));
+    if (vec4_ok(N, Y, R, Out, keep))
+        hipLaunchKernelGGL((bn_apply_fwd_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, keep, keep_scale, Out, M, N, rpc);
     else
-        hipLaunchKernelGGL((bn_apply_fwd_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, Out, M, N, rpc);
+        hipLaunchKernelGGL((bn_apply_fwd_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, keep, keep_scale, Out, M, N, rpc);
     return check_launch("bn_apply_fwd");
 }
 
@@ -294,6 +334,7 @@ BTVAE_API int btvae_bn_apply_fwd(const float* Y, const float* mean, const float*
 // Writes dgamma, dbeta ((+)= when accumulate), dPre = dL/d(pre-ReLU linear output) and dbias = column sums of dPre.
 // `scratch` needs 3 * btvae_strip_chunks(M) * N floats.
 BTVAE_API int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mean, const float* invstd, const float* gamma,
+                                const unsigned char* keep, float keep_scale,
                                 float* dgamma, float* dbeta, float* dbias, float* dPre, float* scratch, int M, int N,
                                 int accumulate, void* stream) {
     BTVAE_REQUIRE(G && Y && mean && invstd && gamma && dgamma && dbeta && dbias && dPre && scratch, "bn_relu_bwd: null pointer");
@@ -301,18 +342,29 @@ BTVAE_API int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mea
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
     float* p2 = scratch;                          // [chunks][2][N]
     float* p1 = scratch + (size_t)2 * chunks * N;   // [chunks][N]
-    const bool v4 = vec4_ok(N, G, Y, dPre, nullptr);
-    ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 5);
-    if (v4) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, p2, M, N, rpc);
-    else    hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, p2, M, N, rpc);
+    const bool v4 = vec4_ok(N, G, Y, dPre, keep);
+    ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 5 + (keep ? 2.0 * M * N : 0.0));
+    if (v4) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, p2, M, N, rpc);
+    else    hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, p2, M, N, rpc);
     // k=0 -> sum g (dbeta), k=1 -> sum g*xhat (dgamma); current-batch values go to the tail of the scratch
     float* cur_dbeta = scratch + (size_t)3 * chunks * N;
     float* cur_dgamma = cur_dbeta + N;
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, p2, chunks, 2, N, dbeta, dgamma, cur_dbeta, cur_dgamma, accumulate);
-    if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, dPre, p1, M, N, rpc);
-    else    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, dPre, p1, M, N, rpc);
+    if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc);
+    else    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, p1, chunks, 1, N, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
     return check_launch("bn_relu_bwd");
+}
+
+// keep[i] = 1 with probability 1-p (train-mode dropout flags of one unit), from Philox(seed, offset).
+BTVAE_API int btvae_dropout_keep_mask(unsigned char* keep, long long n, float p, unsigned long long seed,
+                                      unsigned long long offset, void* stream) {
+    BTVAE_REQUIRE(keep && n > 0, "dropout_keep_mask: null pointer or empty");
+    BTVAE_REQUIRE(p >= 0.f && p < 1.f, "dropout_keep_mask: p=%g outside [0,1)", (double)p);
+    ProfScope ps(PK_BN, (hipStream_t)stream, 0, 1.0 * n);
+    const long long quads = (n + 3) / 4;
+    hipLaunchKernelGGL(dropout_keep_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keep, n, p, seed, offset);
+    return check_launch("dropout_keep_mask");
 }
 
 // Scratch floats btvae_bn_relu_bwd needs for an [M,N] activation.

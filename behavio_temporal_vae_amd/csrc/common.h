@@ -44,6 +44,22 @@ inline int check_launch(const char* what) {
 #define BTVAE_REQUIRE(cond, ...) do { if (!(cond)) return btvae::set_error(__VA_ARGS__); } while (0)
 #define BTVAE_API extern "C" __attribute__((visibility("default")))
 
+// Philox4x32-10 counter RNG: 128 random bits per (seed, offset, index)
+__device__ __forceinline__ uint4 philox4x32(unsigned long long seed, unsigned long long offset, unsigned long long idx) {
+    unsigned c0 = (unsigned)idx, c1 = (unsigned)(idx >> 32), c2 = (unsigned)offset, c3 = (unsigned)(offset >> 32);
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -17,19 +17,9 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 
 // ---- Philox4x32-10 counter RNG -> one standard normal per (seed, offset, index) ----
 __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned long long offset, unsigned long long idx) {
-    unsigned c0 = (unsigned)idx, c1 = (unsigned)(idx >> 32), c2 = (unsigned)offset, c3 = (unsigned)(offset >> 32);
-    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
-        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
-        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    const float u1 = ((float)c0 + 0.5f) * 2.3283064365386963e-10f;   // (0,1)
-    const float u2 = ((float)c1 + 0.5f) * 2.3283064365386963e-10f;
+    const uint4 c = philox4x32(seed, offset, idx);
+    const float u1 = ((float)c.x + 0.5f) * 2.3283064365386963e-10f;   // (0,1)
+    const float u2 = ((float)c.y + 0.5f) * 2.3283064365386963e-10f;
     return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
 }
 

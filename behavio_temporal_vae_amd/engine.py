@@ -39,6 +39,8 @@ class Saved:
     y: Optional[torch.Tensor] = None
     mean: Optional[torch.Tensor] = None
     invstd: Optional[torch.Tensor] = None
+    keep: Optional[torch.Tensor] = None      # uint8 dropout keep flags of the unit's output
+    keep_scale: float = 1.0
 
 
 class NetPlan:
@@ -97,9 +99,34 @@ WS = Workspace()
 WGRAD_WS_FLOATS = 32 * 1024 * 1024
 
 
+class DropoutFeed:
+    """Source of train-mode dropout keep flags (torch.nn.Dropout at src/submodels.py:21): Philox draws on the
+    device seeded from torch's CPU generator, or -- for parity tests -- flags queued in ``injected`` and consumed
+    in the order the units run."""
+
+    def __init__(self):
+        self.injected: Optional[List[torch.Tensor]] = None
+
+    def keep(self, M: int, N: int, p: float, dev) -> torch.Tensor:
+        if self.injected is not None:
+            if not self.injected:
+                raise RuntimeError("dropout: injected keep-flag queue is empty")
+            k = self.injected.pop(0)
+            if tuple(k.shape) != (M, N) or k.dtype != torch.uint8 or k.device != dev or not k.is_contiguous():
+                raise ValueError(f"dropout: injected keep flags must be contiguous uint8 [{M},{N}] on {dev}")
+            return k
+        k = torch.empty(M, N, dtype=torch.uint8, device=dev)
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        nv.call("btvae_dropout_keep_mask", P(k), M * N, float(p), seed, 0)
+        return k
+
+
+DROPOUT = DropoutFeed()
+
+
 def _check_train_supported(u: Unit, train: bool):
-    if train and u.dropout_p > 0.0:
-        raise NotImplementedError("train-mode dropout is not implemented in the HIP path (use dropout: false, or eval mode)")
+    if train and u.dropout_p >= 1.0:
+        raise ValueError("dropout probability must be below 1")
     if train and u.act and u.bn is None:
         raise NotImplementedError("training without batch normalisation is not implemented in the HIP path")
 
@@ -123,9 +150,13 @@ def unit_forward(u: Unit, x: torch.Tensor, train: bool, saved: Optional[List[Sav
         mom = u.bn.momentum if u.bn.momentum is not None else 0.1
         nv.call("btvae_bn_stats_finalize", P(part), tiles, M, N, P(mean), P(invstd),
                 P(u.bn.running_mean) if track else None, P(u.bn.running_var) if track else None, float(mom), float(u.bn.eps))
-        nv.call("btvae_bn_apply_fwd", P(y), P(mean), P(invstd), P(u.bn.weight), P(u.bn.bias), P(x) if u.residual else None, P(out), M, N)
+        keep, ks = None, 1.0
+        if u.dropout_p > 0.0:
+            keep, ks = DROPOUT.keep(M, N, u.dropout_p, dev), 1.0 / (1.0 - u.dropout_p)
+        nv.call("btvae_bn_apply_fwd", P(y), P(mean), P(invstd), P(u.bn.weight), P(u.bn.bias), P(x) if u.residual else None,
+                P(keep), ks, P(out), M, N)
         if saved is not None:
-            saved.append(Saved(x, y, mean, invstd))
+            saved.append(Saved(x, y, mean, invstd, keep, ks))
     else:
         scale = shift = None
         if u.bn is not None:
@@ -192,7 +223,8 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
     dev = g.device
     scr = WS.get("bnbwd", nv.lib().btvae_bn_relu_bwd_scratch(M, N), dev)
     dpre = torch.empty(M, N, device=dev)
-    nv.call("btvae_bn_relu_bwd", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)),
+    nv.call("btvae_bn_relu_bwd", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
+            P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)),
             P(_grad_view(u.lin.bias)), P(dpre), P(scr), M, N, int(accumulate))
     ws = WS.get("wgrad", WGRAD_WS_FLOATS, dev)
     nv.call("btvae_linear_wgrad", P(dpre), P(sv.x_in), K, P(_grad_view(u.lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))

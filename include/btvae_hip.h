@@ -63,14 +63,21 @@ int btvae_bn_stats_finalize(const float* partials, int ntiles, int M, int N, flo
 /* Eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale. */
 int btvae_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, float* scale, float* shift, int N, void* stream);
-/* Out = (Y-mean)*invstd*gamma + beta (+ R): normalisation and the residual add of src/submodels.py:32. */
+/* keep[i] = 1 with probability 1-p from Philox(seed, offset): the Bernoulli flags of one train-mode
+ * torch.nn.Dropout(p) call (src/submodels.py:21). */
+int btvae_dropout_keep_mask(unsigned char* keep, long long n, float p, unsigned long long seed,
+                            unsigned long long offset, void* stream);
+/* Out = dropout((Y-mean)*invstd*gamma + beta) (+ R): normalisation, optional dropout (keep NULL = none;
+ * kept elements are scaled by keep_scale = 1/(1-p)) and the residual add of src/submodels.py:21,32. */
 int btvae_bn_apply_fwd(const float* Y, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                       const float* R, float* Out, int M, int N, void* stream);
-/* Backward of ReLU -> BatchNorm(train): from G = dL/dOut and the saved Y (post-ReLU) produce dgamma, dbeta,
- * dbias (column sums of dPre) and dPre = dL/d(Linear output).  scratch: btvae_bn_relu_bwd_scratch(M,N) floats. */
+                       const float* R, const unsigned char* keep, float keep_scale, float* Out, int M, int N,
+                       void* stream);
+/* Backward of ReLU -> BatchNorm(train) (-> Dropout): from G = dL/dOut, the saved Y (post-ReLU) and the
+ * forward's keep flags (NULL = no dropout) produce dgamma, dbeta, dbias (column sums of dPre) and
+ * dPre = dL/d(Linear output).  scratch: btvae_bn_relu_bwd_scratch(M,N) floats. */
 long long btvae_bn_relu_bwd_scratch(int M, int N);
 int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mean, const float* invstd, const float* gamma,
-                      float* dgamma, float* dbeta, float* dbias, float* dPre, float* scratch, int M, int N,
+                      const unsigned char* keep, float keep_scale, float* dgamma, float* dbeta, float* dbias, float* dPre, float* scratch, int M, int N,
                       int accumulate, void* stream);
 /* out[N] (+)= column sums of G[M,N]; scratch: btvae_strip_chunks(M)*N floats. */
 int btvae_colsum(const float* G, float* out, float* scratch, int M, int N, int accumulate, void* stream);

@@ -71,9 +71,34 @@ class Cdim:
     def __init__(self, c): self.cond_dim = c
 
 
-def case_forward_train(name, lik, seed, D=6, C=4, B=8, S=3, three_d=False, steps=4):
+class DropLog:
+    """While active, ``torch.nn.Dropout`` modules draw their scaled mask with torch's own dropout applied to a
+    tensor of ones, multiply the input by it, and the keep flags are recorded in call order."""
+    def __init__(self):
+        self.keep = []
+
+    def __enter__(self):
+        self._fwd = torch.nn.Dropout.forward
+        log = self
+        def forward(mod, x):
+            if not mod.training or mod.p == 0.0:
+                return x
+            m = torch.nn.functional.dropout(torch.ones_like(x), mod.p, True)
+            log.keep.append((m != 0).to(torch.uint8).numpy())
+            return x * m
+        torch.nn.Dropout.forward = forward
+        return self
+
+    def __exit__(self, *exc):
+        torch.nn.Dropout.forward = self._fwd
+
+
+def case_forward_train(name, lik, seed, D=6, C=4, B=8, S=3, three_d=False, steps=4, dropout=False):
     rng = np.random.default_rng(seed)
     cfg = tiny_model_cfg(lik)
+    if dropout:
+        for d in cfg["distribution_dict"].values():
+            d["dropout"] = True
     torch.manual_seed(seed)
     model = CVAE(input_dim=D, conditioner=Cdim(C), **cfg)
     L = cfg["latent_dim"]
@@ -96,7 +121,13 @@ def case_forward_train(name, lik, seed, D=6, C=4, B=8, S=3, three_d=False, steps
         torch.manual_seed(seed + 100)
         eps = torch.randn((S, B, L)) if not three_d else torch.randn((1, S, B, L))
         torch.manual_seed(seed + 100)
-        xd, zd = m2.forward(x, c, num_mc_samples=S)
+        with DropLog() as dl, DrawLog() as rl:
+            xd, zd = m2.forward(x, c, num_mc_samples=S)
+        if dropout:      # dropout draws come first in the stream, so take the noise the forward really used
+            eps = rl.randn[0]
+        if mode == "train":
+            for i, k in enumerate(dl.keep):
+                out[f"train_keep_{i}"] = k
         loss = m2.loss(x, xd["params"], zd["params"], beta=0.7, prior_params=m2.prior_params)
         out[f"{mode}_eps"] = eps.reshape(S, B, L).numpy()
         out[f"{mode}_lik_mu"] = xd["params"]["mu"].detach().numpy()
@@ -136,7 +167,12 @@ def case_forward_train(name, lik, seed, D=6, C=4, B=8, S=3, three_d=False, steps
             torch.manual_seed(seed + 1000 + t)
             eps = torch.randn((S, B, L))
             torch.manual_seed(seed + 1000 + t)
-            loss = m3.train_core((xb, cb), optim)
+            with DropLog() as dl, DrawLog() as rl:
+                loss = m3.train_core((xb, cb), optim)
+            if dropout:
+                eps = rl.randn[0]
+            for i, k in enumerate(dl.keep):
+                out[f"step{t}_keep_{i}"] = k
             xs.append(xb.numpy()); cs.append(cb.numpy()); es.append(eps.numpy())
             ls.append([loss[k].item() for k in ("loss", "elbo", "rll", "kl")])
         out["steps_x"], out["steps_c"], out["steps_eps"] = np.stack(xs), np.stack(cs), np.stack(es)
@@ -329,11 +365,15 @@ def case_conditioner(name="conditioner"):
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "dropout":      # only the dropout case (leaves the other fixtures as they are)
+        case_forward_train("tiny_dropout_2d", "dict-gauss", seed=6, B=16, dropout=True)
+        sys.exit(0)
     case_pointwise()
     case_conditioner()
     case_forward_train("tiny_dict_2d", "dict-gauss", seed=1)
     case_forward_train("tiny_dict_3d", "dict-gauss", seed=2, three_d=True)
     case_forward_train("tiny_normal_2d", "normal", seed=3)
+    case_forward_train("tiny_dropout_2d", "dict-gauss", seed=6, B=16, dropout=True)
     case_scoring()
     case_imputation()
     case_config0_shape()

@@ -225,19 +225,27 @@ def linear_relu_bn(sd: Dict[str, Tensor], lay: LayerRef, h: Tensor, bn: bool, tr
 
 
 def parameterizer_forward(sd: Dict[str, Tensor], net: str, ds: DistSpec, inputs: Tensor, train: bool,
-                          bn_updates: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
+                          bn_updates: Optional[Dict[str, Tensor]] = None,
+                          keep_flags: Optional[List[Tensor]] = None) -> Dict[str, Tensor]:
     """``ParameterizerNN.forward`` (src/submodels.py:63-69): flatten to rows, shared trunk, then
-    one two-layer head per distribution parameter.  Dropout is treated as inactive (oracle cases use
-    ``dropout: false`` or eval mode)."""
+    one two-layer head per distribution parameter.  Train-mode dropout (src/submodels.py:23-25,51)
+    takes its Bernoulli keep flags from the front of ``keep_flags`` (one 0/1 tensor per
+    Linear-ReLU-BN unit, in execution order); with ``keep_flags=None`` dropout is inactive."""
     trunk, heads = network_layers(net, ds)
     h = inputs.reshape(-1, ds.in_dim)
+
+    def mask_for(lay):
+        if not (train and ds.dropout and lay.act_bn and keep_flags is not None):
+            return None
+        return keep_flags.pop(0).to(h.dtype) / (1.0 - ds.dropout_rate)
+
     for lay in trunk:
-        h = linear_relu_bn(sd, lay, h, ds.bn, train, bn_updates)
+        h = linear_relu_bn(sd, lay, h, ds.bn, train, bn_updates, mask_for(lay))
     out = {}
     for name, lays in heads.items():
         t = h
         for lay in lays:
-            t = linear_relu_bn(sd, lay, t, ds.bn, train, bn_updates)
+            t = linear_relu_bn(sd, lay, t, ds.bn, train, bn_updates, mask_for(lay))
         out[name] = t
     return out
 
@@ -248,11 +256,12 @@ def softplus_thr(x: Tensor, threshold: float = 5.0) -> Tensor:
 
 
 def dist_forward(sd: Dict[str, Tensor], net: str, ds: DistSpec, inputs: Tensor, train: bool,
-                 bn_updates: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
+                 bn_updates: Optional[Dict[str, Tensor]] = None,
+                 keep_flags: Optional[List[Tensor]] = None) -> Dict[str, Tensor]:
     """``GaussianNN.forward`` (src/submodels.py:100-106) / ``DictionaryGaussian.forward``
     (src/submodels.py:154-158): clamp mu; sigma = clamp(softplus(.)) for the Gaussian,
     clamp(relu(.)) for the dictionary Gaussian."""
-    raw = parameterizer_forward(sd, net, ds, inputs, train, bn_updates)
+    raw = parameterizer_forward(sd, net, ds, inputs, train, bn_updates, keep_flags)
     mu = raw["mu"].clamp(ds.mu_lo, ds.mu_hi)
     if ds.kind == "dict":
         sigma = torch.relu(raw["sigma"]).clamp(ds.sig_lo, ds.sig_hi)
@@ -315,7 +324,7 @@ def dict_rsample(U: Tensor, mu: Tensor, sigma: Tensor, eps: Tensor) -> Tensor:
 # model forward / loss
 # ---------------------------------------------------------------------------------------------
 def cvae_forward(sd: Dict[str, Tensor], spec: ModelSpec, x: Tensor, c: Tensor, eps: Tensor, train: bool,
-                 bn_updates: Optional[Dict[str, Tensor]] = None):
+                 bn_updates: Optional[Dict[str, Tensor]] = None, keep_flags: Optional[List[Tensor]] = None):
     """``CVAE.forward`` (src/vae_models.py:260-280).
 
     2-D conditions ``c[B,C]``: encoder on B rows, ``z = mu + sigma*eps`` with ``eps[S,B,L]``, decoder
@@ -324,7 +333,7 @@ def cvae_forward(sd: Dict[str, Tensor], spec: ModelSpec, x: Tensor, c: Tensor, e
     (likelihood params ``[S,B,·]``, posterior params, z)."""
     if c.ndim == 2:
         S, B = eps.shape[0], x.shape[0]
-        post = dist_forward(sd, "encoder", spec.enc, torch.cat((x, c), -1), train, bn_updates)
+        post = dist_forward(sd, "encoder", spec.enc, torch.cat((x, c), -1), train, bn_updates, keep_flags)
         z = post["mu"] + post["sigma"] * eps
         dec_in = torch.cat((z, c.unsqueeze(0).expand(S, B, c.shape[-1])), 2)
     elif c.ndim == 3:
@@ -332,13 +341,13 @@ def cvae_forward(sd: Dict[str, Tensor], spec: ModelSpec, x: Tensor, c: Tensor, e
         if c.shape[1] != S:
             raise ValueError("Condition samples must be equal to number of posterior MC samples.")
         ct = c.transpose(1, 0)
-        post = dist_forward(sd, "encoder", spec.enc, torch.cat((x.unsqueeze(0).expand(S, B, x.shape[-1]), ct), -1), train, bn_updates)
+        post = dist_forward(sd, "encoder", spec.enc, torch.cat((x.unsqueeze(0).expand(S, B, x.shape[-1]), ct), -1), train, bn_updates, keep_flags)
         post = {k: v.view(S, B, -1) for k, v in post.items()}
         z = post["mu"] + post["sigma"] * eps
         dec_in = torch.cat((z, ct), -1)
     else:
         raise ValueError("Invalid shape for conditions. Must be 2D or 3D tensor.")
-    lik = dist_forward(sd, "decoder", spec.dec, dec_in, train, bn_updates)
+    lik = dist_forward(sd, "decoder", spec.dec, dec_in, train, bn_updates, keep_flags)
     lik = {k: v.view(S, B, -1) for k, v in lik.items()}
     return lik, post, z
 
@@ -386,7 +395,8 @@ def clip_and_adam(sd: Dict[str, Tensor], grads: Dict[str, Tensor], st: AdamState
 
 
 def train_step(sd: Dict[str, Tensor], spec: ModelSpec, st: AdamState, x: Tensor, c: Tensor, eps: Tensor,
-               lr: float, weight_decay: float, beta: float = 1.0, max_norm: Optional[float] = 1.0):
+               lr: float, weight_decay: float, beta: float = 1.0, max_norm: Optional[float] = 1.0,
+               keep_flags: Optional[List[Tensor]] = None):
     """One ``CVAE.train_core`` (src/vae_models.py:317-325): forward in train mode, loss, backward
     (autograd on the restated forward), global-norm clip, Adam.  Mutates ``sd`` and ``st``.
     Returns (loss dict of floats, gradient dict, pre-clip norm)."""
@@ -395,7 +405,7 @@ def train_step(sd: Dict[str, Tensor], spec: ModelSpec, st: AdamState, x: Tensor,
     work = dict(sd)
     work.update(leaves)
     upd: Dict[str, Tensor] = {}
-    lik, post, _ = cvae_forward(work, spec, x, c, eps, True, upd)
+    lik, post, _ = cvae_forward(work, spec, x, c, eps, True, upd, keep_flags)
     terms = elbo_terms(work, spec, x, lik, post, beta)
     gl = torch.autograd.grad(terms["loss"], [leaves[k] for k in keys])
     grads = {k: g.detach() for k, g in zip(keys, gl)}

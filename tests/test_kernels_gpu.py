@@ -132,7 +132,7 @@ def test_batchnorm_fwd_bwd(dev, M, N):
     d = {k: v.to(dev) for k, v in dict(Y=Yr, G=G, R=R, gam=gam, bet=bet).items()}
     mean_d = mean.detach().float().to(dev); inv_d = (1 / torch.sqrt(var.detach() + 1e-5)).float().to(dev)
     o = torch.empty(M, N, device=dev)
-    nv.call("btvae_bn_apply_fwd", P(d["Y"]), P(mean_d), P(inv_d), P(d["gam"]), P(d["bet"]), P(d["R"]), P(o), M, N)
+    nv.call("btvae_bn_apply_fwd", P(d["Y"]), P(mean_d), P(inv_d), P(d["gam"]), P(d["bet"]), P(d["R"]), None, 1.0, P(o), M, N)
     close(o, out, 1e-5, 1e-5, "bn fwd")
     # backward: reference goes through relu as well (y = relu(pre))
     pre = rnd(M, N, seed=1).requires_grad_(True)
@@ -144,7 +144,7 @@ def test_batchnorm_fwd_bwd(dev, M, N):
     scr = torch.empty(nscr, device=dev)
     dgam, dbet, dbias = (torch.zeros(N, device=dev) for _ in range(3))
     dpre = torch.empty(M, N, device=dev)
-    nv.call("btvae_bn_relu_bwd", P(d["G"]), P(d["Y"]), P(mean_d), P(inv_d), P(d["gam"]), P(dgam), P(dbet), P(dbias), P(dpre), P(scr), M, N, 0)
+    nv.call("btvae_bn_relu_bwd", P(d["G"]), P(d["Y"]), P(mean_d), P(inv_d), P(d["gam"]), None, 1.0, P(dgam), P(dbet), P(dbias), P(dpre), P(scr), M, N, 0)
     s = math.sqrt(M)
     close(dpre, pre.grad, 1e-4, 2e-6, "dpre")
     close(dgam, g64.grad, 1e-5, 3e-6 * s, "dgamma")

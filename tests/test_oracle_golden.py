@@ -87,6 +87,48 @@ def test_train_steps(name):
             assert int(v) == int(ref), k
 
 
+def _keep(g, prefix):
+    out, i = [], 0
+    while f"{prefix}_keep_{i}" in g:
+        out.append(T(g[f"{prefix}_keep_{i}"]))
+        i += 1
+    return out
+
+
+def test_dropout_forward_grads_and_steps():
+    """Train-mode dropout with the reference's recorded Bernoulli keep flags: forward terms, every gradient
+    and four optimiser steps."""
+    g = load_golden("tiny_dropout_2d")
+    spec, _ = golden_spec(g)
+    assert spec.enc.dropout and spec.dec.dropout
+    sd = golden_state(g)
+    keys = R.parameter_keys(spec)
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
+    work = dict(sd); work.update(leaves)
+    flags = _keep(g, "train")
+    assert len(flags) == 12
+    lik, post, _ = R.cvae_forward(work, spec, T(g["x"]), T(g["c"]), T(g["train_eps"]), True, {}, flags)
+    assert not flags
+    assert np.allclose(lik["mu"].detach().numpy(), g["train_lik_mu"], rtol=1e-4, atol=2e-5)
+    terms = R.elbo_terms(work, spec, T(g["x"]), lik, post, beta=0.7)
+    for k in ("loss", "elbo", "rll", "kl"):
+        assert abs(float(terms[k]) - float(g[f"train_{k}"])) <= 1e-4 * abs(float(g[f"train_{k}"])) + 1e-5
+    grads = torch.autograd.grad(terms["loss"], [leaves[k] for k in keys])
+    for k, gr in zip(keys, grads):
+        ref = g["grad::" + k]
+        assert np.abs(gr.numpy() - ref).max() <= 2e-4 * (np.abs(ref).max() + 1e-8) + 1e-6, k
+    st = R.AdamState()
+    for t in range(g["steps_x"].shape[0]):
+        terms, _, _ = R.train_step(sd, spec, st, T(g["steps_x"][t]), T(g["steps_c"][t]), T(g["steps_eps"][t]),
+                                   lr=1e-3, weight_decay=1e-5, beta=0.7, max_norm=1.0, keep_flags=_keep(g, f"step{t}"))
+        got = [terms[k] for k in ("loss", "elbo", "rll", "kl")]
+        assert rel_err(got, g["steps_losses"][t]) < 1e-4, (t, got, g["steps_losses"][t])
+    for k, v in sd.items():
+        ref = g["final::" + k]
+        if v.is_floating_point():
+            assert np.abs(v.numpy() - ref).max() <= 2e-4 * (np.abs(ref).max() + 1e-6), k
+
+
 def test_scoring():
     g = load_golden("scoring_tiny")
     spec, _ = golden_spec(g)
