@@ -11,7 +11,8 @@ from ctypes import c_double, c_float, c_int, c_longlong, c_ulonglong, c_void_p
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbtvae_hip.so")
+# BTVAE_HIP_LIB points at another build of the same library (kernel experiments); default is the in-tree build
+_LIB_PATH = os.environ.get("BTVAE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbtvae_hip.so")
 _lib = None
 _inited = set()
 
@@ -22,6 +23,8 @@ _SIGS = {
     "btvae_init": [I],
     "btvae_prof_enable": [I],
     "btvae_prof_collect": [P, P, P, P, I],
+    "btvae_prof_dominant": [I, P, P, P],
+    "btvae_set_gemm_precision": [I],
     "btvae_linear_relu_stats_fwd": [P, I, P, P, P, P, I, I, I, P],
     "btvae_linear_relu_affine_fwd": [P, I, P, P, P, P, P, P, I, I, I, P],
     "btvae_linear_head_fwd": [P, I, P, P, I, F, F, P, P, P, I, I, I, P],
@@ -56,6 +59,7 @@ _SIGS = {
     "btvae_pack_lower": [P, P, LL, I, P],
 }
 _RET = {
+    "btvae_get_gemm_precision": (c_int, []),
     "btvae_last_error": (ctypes.c_char_p, []),
     "btvae_version": (c_int, []),
     "btvae_strip_chunks": (c_int, [I]),
@@ -127,8 +131,35 @@ def f32(t, name="tensor"):
     return t.contiguous()
 
 
+GEMM_PRECISIONS = {"fp32": 0, "bf16": 1}
+
+
+def set_gemm_precision(name: str):
+    """Operand precision of the Linear-layer products: ``"fp32"`` (default) or ``"bf16"`` (bf16 operands, fp32
+    accumulation).  Process-wide."""
+    if name not in GEMM_PRECISIONS:
+        raise ValueError(f"unknown GEMM precision {name!r}; choose from {sorted(GEMM_PRECISIONS)}")
+    if lib().btvae_set_gemm_precision(GEMM_PRECISIONS[name]) != 0:
+        raise RuntimeError(last_error())
+
+
+def get_gemm_precision() -> str:
+    mode = lib().btvae_get_gemm_precision()
+    return next(k for k, v in GEMM_PRECISIONS.items() if v == mode)
+
+
 def prof_enable(on: bool):
     lib().btvae_prof_enable(1 if on else 0)
+
+
+def prof_dominant(kind: str):
+    """(ms summed, flops of one launch, launches) of the launches of ``kind`` with the largest FLOP count;
+    call after a device sync and before ``prof_collect``."""
+    ms, fl, cnt = c_double(), c_double(), c_longlong()
+    rc = lib().btvae_prof_dominant(PROF_KINDS.index(kind), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt))
+    if rc != 0:
+        raise RuntimeError(last_error())
+    return ms.value, fl.value, cnt.value
 
 
 def prof_collect():

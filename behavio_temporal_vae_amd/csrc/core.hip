@@ -77,6 +77,21 @@ BTVAE_API int btvae_prof_enable(int on) {
     return 0;
 }
 
+// After a device synchronisation and before btvae_prof_collect: within one family, the launches that carry the
+// largest FLOP count (the family's dominant shape) -- summed milliseconds, FLOPs of one such launch, launches.
+BTVAE_API int btvae_prof_dominant(int kind, double* ms, double* flops_per_launch, long long* count) {
+    BTVAE_REQUIRE(kind >= 0 && kind < PK_COUNT && ms && flops_per_launch && count, "prof_dominant: bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    double top = 0.0;
+    for (auto& r : g_recs) if (r.kind == kind && r.flops > top) top = r.flops;
+    *ms = 0.0; *flops_per_launch = top; *count = 0;
+    for (auto& r : g_recs) {
+        float t = 0.f;
+        if (r.kind == kind && r.flops >= 0.999 * top && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { *ms += t; *count += 1; }
+    }
+    return 0;
+}
+
 // After a device synchronisation: per family, summed milliseconds, FLOPs, bytes and launch counts
 // (arrays of PK_COUNT = 8 entries each).  Clears the records.
 BTVAE_API int btvae_prof_collect(double* ms, double* flops, double* bytes, long long* count, int n) {

@@ -11,17 +11,19 @@
 // k index fed to MFMA number q of a k-tile by lane half h is (q/4)*8 + 4h + q%4 for BOTH operands,
 // which makes the k-contiguous fragment a single 16-byte LDS read.  The f32 MFMA runs at the f32
 // vector rate (64 FLOP/clk/SIMD), so the kernel is MFMA-issue bound; LDS and L2 have >4x slack.
-#include "common.h"
+#include "gemm_common.h"
+#include "gemm_bf16.h"
 #include <algorithm>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include <atomic>
 
 namespace {
+
+using namespace btvae_gemm;
 
 #ifndef BTVAE_GEMM_BK
 #define BTVAE_GEMM_BK 16      // k-tile depth: 16 -> 40 KB of LDS per workgroup (3 workgroups per CU), 32 -> 72 KB (2 per CU)
 #endif
-constexpr int BM = 128, BN = 128, BK = BTVAE_GEMM_BK;
+constexpr int BK = BTVAE_GEMM_BK;
 constexpr int NQ = BK / 8;              // 16-byte staging loads per operand per thread per k-tile
 constexpr int NG = BK / 8;              // k-groups (8 k = 4 MFMA steps x 2 lane halves) per k-tile
 constexpr int LDK = BK + 4;             // row stride (floats) of a k-contiguous LDS tile: 16-B slots 9 apart -> conflict-free b128
@@ -29,25 +31,7 @@ constexpr int LDM = 128 + 4;            // row stride of an m/n-contiguous LDS t
 constexpr int TILE_FLOATS = (128 * LDK > BK * LDM) ? 128 * LDK : BK * LDM;
 constexpr int KC4 = BK / 4;             // 16-byte chunks per row of a k-contiguous tile
 
-enum { LAY_K = 0, LAY_M = 1 };
-enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_RELU_STATS = 2, EPI_RELU_AFFINE = 3, EPI_HEAD = 4, EPI_MUL = 5 };
 
-struct GemmArgs {
-    const float* A; const float* B; float* C;
-    int lda, ldb, ldc;
-    int M, N, K;
-    int kchunk;                 // reduction elements per blockIdx.z (multiple of BK)
-    size_t slab_stride;         // C elements between z slabs
-    const float* bias;          // [N]
-    const float* scale; const float* shift;   // [N]  (EPI_RELU_AFFINE; null = identity)
-    const float* R; int ldr;    // add-in [M,N]       (EPI_PLAIN / EPI_RELU_AFFINE; null = none)
-    float* C2; float* C3;       // EPI_HEAD: derivative factor, squared value (either may be null)
-    float* stats;               // EPI_RELU_STATS: [tiles_m][2][N] = per-tile column (mean, M2)
-    const float* E1; const float* E2; int lde;  // EPI_MUL
-    int act; float lo, hi;      // EPI_HEAD
-    int a_vec, b_vec;
-    int tiles_m, tiles_n;
-};
 
 // Vector path (rows 16-byte aligned, contiguous extent and leading dimension multiples of 4): one predicated
 // 16-byte load per chunk into a zero-initialised register, no use of the data before the LDS write, so all
@@ -72,6 +56,22 @@ __device__ __forceinline__ void g2r_vec(const float* __restrict__ P, int ld, int
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) v = *reinterpret_cast<const float4*>(P + off);
         st[q] = v;
+    }
+}
+
+// Steady-state variant for k-tiles that lie wholly inside [kbeg, kend): no predicate at all.  Rows past the
+// matrix edge are clamped to the last valid row (or row quad), so the loads stay in bounds; what they fetch only
+// feeds accumulator rows / columns the epilogue never stores.
+template <int LAY>
+__device__ __forceinline__ void g2r_vec_full(const float* __restrict__ P, int ld, int row0, int nrows, int k0,
+                                             int tid, float4 (&st)[NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int f = tid + 256 * q;
+        size_t off;
+        if (LAY == LAY_K) off = (size_t)min(row0 + f / KC4, nrows - 1) * ld + (k0 + ((f % KC4) << 2));
+        else              off = (size_t)(k0 + (f >> 5)) * ld + min(row0 + ((f & 31) << 2), nrows - 4);
+        st[q] = *reinterpret_cast<const float4*>(P + off);
     }
 }
 
@@ -132,15 +132,17 @@ __device__ __forceinline__ float4 frag(const float* S, int rc, int g, int lh) {
     return make_float4(q[0], q[LDM], q[2 * LDM], q[3 * LDM]);
 }
 
-__device__ __forceinline__ float softplus5(float x) { return x > 5.f ? x : log1pf(expf(x)); }
 
 #ifndef BTVAE_GEMM_NBUF
 #define BTVAE_GEMM_NBUF 2     // LDS buffers per operand: 1 = 36 KB per workgroup (3 workgroups per CU), 2 = 72 KB (2 per CU)
 #endif
 constexpr int NBUF = BTVAE_GEMM_NBUF;
+#ifndef BTVAE_GEMM_MINWG
+#define BTVAE_GEMM_MINWG ((BTVAE_GEMM_NBUF == 1 || BTVAE_GEMM_BK == 16) ? 3 : 2)   // workgroups per CU the register budget is set for
+#endif
 
 template <int AL, int BL, int EPI, bool VEC>
-__global__ __launch_bounds__(256, (NBUF == 1 || BK == 16) ? 3 : 2) void gemm_f32_mfma(const GemmArgs p) {
+__global__ __launch_bounds__(256, BTVAE_GEMM_MINWG) void gemm_f32_mfma(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[NBUF][2][TILE_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
@@ -202,8 +204,14 @@ __global__ __launch_bounds__(256, (NBUF == 1 || BK == 16) ? 3 : 2) void gemm_f32
     for (; t + 1 < nk; ++t) {
         const int cur = NBUF == 2 ? (t & 1) : 0;
         const int k0 = kbeg + t * BK;
-        g2r<AL, VEC>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, sa);
-        g2r<BL, VEC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, sb);
+        if (VEC && t + 2 < nk) {        // tile t+1 is a full one
+            g2r_vec_full<AL>(p.A, p.lda, m0, p.M, k0 + BK, tid, sa);
+            g2r_vec_full<BL>(p.B, p.ldb, n0, p.N, k0 + BK, tid, sb);
+        } else {
+            g2r<AL, VEC>(p.A, p.lda, m0, p.M, k0 + BK, kend, tid, sa);
+            g2r<BL, VEC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, tid, sb);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // loads first, so the whole tile's MFMAs cover their latency
         const float* As = smem[cur][0];
         const float* Bs = smem[cur][1];
         float4 a0[2], b0[2], a1[2], b1[2];
@@ -215,6 +223,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 || BK == 16) ? 3 : 2) void gemm_f32
             if (g + 2 < NG) load_group(As, Bs, g + 2, a0, b0);
             mma_group(a1, b1);
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the LDS publish (and its wait on the loads) after the MFMAs
         if (NBUF == 2) {
             r2s<AL>(smem[cur ^ 1][0], tid, sa);
             r2s<BL>(smem[cur ^ 1][1], tid, sb);
@@ -240,128 +249,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 || BK == 16) ? 3 : 2) void gemm_f32
         __syncthreads();
     }
 
-    // ---- epilogue: accumulator element r of tile (rb,cb) is row (r&3)+8(r>>2)+4*lh, column li ----
-    float colv[2][3];   // per-column vectors: bias / scale / shift
-    int colg[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int col = n0 + wc * 64 + cb * 32 + li;
-        colg[cb] = col;
-        const bool ok = col < p.N;
-        colv[cb][0] = (EPI == EPI_BIAS || EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE || EPI == EPI_HEAD) && ok && p.bias ? p.bias[col] : 0.f;
-        colv[cb][1] = (EPI == EPI_RELU_AFFINE && ok && p.scale) ? p.scale[col] : 1.f;
-        colv[cb][2] = (EPI == EPI_RELU_AFFINE && ok && p.shift) ? p.shift[col] : 0.f;
-    }
-    float* Cz = p.C + (size_t)blockIdx.z * p.slab_stride;
-
-    float st_n[2], st_mean[2], st_m2[2];   // EPI_RELU_STATS: this lane's (count, mean, M2) per column block
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int col = colg[cb];
-        float shiftK = 0.f, s = 0.f, q = 0.f, cnt = 0.f;
-        bool have = false;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const bool ok = row < p.M && col < p.N;
-                float v = acc[rb][cb][r];
-                if (EPI == EPI_PLAIN) {
-                    if (ok) {
-                        if (p.R) v += p.R[(size_t)row * p.ldr + col];
-                        Cz[(size_t)row * p.ldc + col] = v;
-                    }
-                } else if (EPI == EPI_BIAS) {
-                    if (ok) {
-                        v += colv[cb][0];
-                        if (p.R) v += p.R[(size_t)row * p.ldr + col];
-                        Cz[(size_t)row * p.ldc + col] = v;
-                    }
-                } else if (EPI == EPI_RELU_STATS) {
-                    v = fmaxf(v + colv[cb][0], 0.f);
-                    if (ok) {
-                        Cz[(size_t)row * p.ldc + col] = v;
-                        if (!have) { shiftK = v; have = true; }
-                        const float d = v - shiftK;
-                        s += d; q += d * d; cnt += 1.f;
-                    }
-                } else if (EPI == EPI_RELU_AFFINE) {
-                    v = fmaxf(v + colv[cb][0], 0.f) * colv[cb][1] + colv[cb][2];
-                    if (ok) {
-                        if (p.R) v += p.R[(size_t)row * p.ldr + col];
-                        Cz[(size_t)row * p.ldc + col] = v;
-                    }
-                } else if (EPI == EPI_HEAD) {
-                    const float raw = v + colv[cb][0];
-                    float val, df;
-                    if (p.act == 0) {            // clamp
-                        val = fminf(fmaxf(raw, p.lo), p.hi);
-                        df = (raw >= p.lo && raw <= p.hi) ? 1.f : 0.f;
-                    } else if (p.act == 1) {     // clamp(softplus(raw; threshold 5))
-                        const float sp = softplus5(raw);
-                        val = fminf(fmaxf(sp, p.lo), p.hi);
-                        df = (sp >= p.lo && sp <= p.hi) ? (raw > 5.f ? 1.f : 1.f / (1.f + expf(-raw))) : 0.f;
-                    } else {                     // clamp(relu(raw))
-                        const float rl = fmaxf(raw, 0.f);
-                        val = fminf(fmaxf(rl, p.lo), p.hi);
-                        df = (raw > 0.f && rl >= p.lo && rl <= p.hi) ? 1.f : 0.f;
-                    }
-                    if (ok) {
-                        const size_t o = (size_t)row * p.ldc + col;
-                        Cz[o] = val;
-                        if (p.C2) p.C2[o] = df;
-                        if (p.C3) p.C3[o] = val * val;
-                    }
-                } else if (EPI == EPI_MUL) {
-                    if (ok) {
-                        const size_t e = (size_t)row * p.lde + col;
-                        Cz[(size_t)row * p.ldc + col] = v * p.E1[e] * p.E2[e];
-                    }
-                }
-            }
-        }
-        if (EPI == EPI_RELU_STATS) {
-            float mean = 0.f, m2 = 0.f;
-            if (cnt > 0.f) { mean = shiftK + s / cnt; m2 = fmaxf(q - s * s / cnt, 0.f); }
-            // merge the two lane halves (rows +4): Chan's pairwise update
-            const float on = __shfl_xor(cnt, 32, 64), om = __shfl_xor(mean, 32, 64), o2 = __shfl_xor(m2, 32, 64);
-            const float n = cnt + on;
-            if (n > 0.f) {
-                const float dlt = om - mean;
-                m2 = m2 + o2 + dlt * dlt * (cnt * on / n);
-                mean = (cnt * mean + on * om) / n;
-            }
-            st_n[cb] = n; st_mean[cb] = mean; st_m2[cb] = m2;
-        }
-    }
-
-    if (EPI == EPI_RELU_STATS) {
-        float* red = &smem[0][0][0];   // [wr][3][128]; the k-loop's last barrier has retired all tile reads
-        if (lh == 0) {
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int c = wc * 64 + cb * 32 + li;
-                red[(wr * 3 + 0) * 128 + c] = st_n[cb];
-                red[(wr * 3 + 1) * 128 + c] = st_mean[cb];
-                red[(wr * 3 + 2) * 128 + c] = st_m2[cb];
-            }
-        }
-        __syncthreads();
-        if (tid < 128 && n0 + tid < p.N) {
-            const float na = red[0 * 128 + tid], ma = red[1 * 128 + tid], qa = red[2 * 128 + tid];
-            const float nb = red[3 * 128 + tid], mb = red[4 * 128 + tid], qb = red[5 * 128 + tid];
-            const float n = na + nb;
-            float mean = ma, m2 = qa;
-            if (nb > 0.f) {
-                const float dlt = mb - ma;
-                m2 = qa + qb + dlt * dlt * (na * nb / n);
-                mean = (na * ma + nb * mb) / n;
-            }
-            p.stats[((size_t)tile_m * 2 + 0) * p.N + n0 + tid] = mean;
-            p.stats[((size_t)tile_m * 2 + 1) * p.N + n0 + tid] = m2;
-        }
-    }
+    gemm_epilogue<EPI>(p, acc, &smem[0][0][0], m0, n0, tile_m);   // the k-loop's last barrier has retired all tile reads
 }
 
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t n, int nslab, size_t stride, int accumulate) {
@@ -376,8 +264,12 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+std::atomic<int> g_precision{0};   // 0: fp32 MFMA, 1: bf16 operands with fp32 accumulation (Linear layers only)
+
+// `reduced_ok`: this product may run with bf16 operands when that mode is selected (Linear fwd/dgrad/wgrad);
+// the covariance products of the likelihood always run in fp32.  On return a.kchunk holds the split length used.
 template <int AL, int BL, int EPI>
-int launch(GemmArgs a, int splits, hipStream_t s, const char* what) {
+int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduced_ok = false) {
     BTVAE_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "%s: empty problem M=%d N=%d K=%d", what, a.M, a.N, a.K);
     BTVAE_REQUIRE(a.A && a.B && a.C, "%s: null operand", what);
     BTVAE_REQUIRE(a.ldc >= a.N, "%s: ldc %d < N %d", what, a.ldc, a.N);
@@ -389,10 +281,13 @@ int launch(GemmArgs a, int splits, hipStream_t s, const char* what) {
     a.a_vec = (a.lda % 4 == 0) && aligned16(a.A) && ((AL == LAY_K ? a.K : a.M) % 4 == 0);
     a.b_vec = (a.ldb % 4 == 0) && aligned16(a.B) && ((BL == LAY_K ? a.K : a.N) % 4 == 0);
     if (splits < 1) splits = 1;
-    a.kchunk = (((a.K + splits - 1) / splits) + BK - 1) / BK * BK;
+    const bool bf16 = reduced_ok && g_precision.load(std::memory_order_relaxed) == 1 && a.a_vec && a.b_vec;
+    const int bk = bf16 ? HBK : BK;
+    a.kchunk = (((a.K + splits - 1) / splits) + bk - 1) / bk * bk;
     splits = (a.K + a.kchunk - 1) / a.kchunk;
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)splits);
-    if (a.a_vec && a.b_vec) hipLaunchKernelGGL((gemm_f32_mfma<AL, BL, EPI, true>), grid, dim3(256), 0, s, a);
+    if (bf16)                    hipLaunchKernelGGL((gemm_bf16_mfma<AL, BL, EPI>), grid, dim3(256), 0, s, a);
+    else if (a.a_vec && a.b_vec) hipLaunchKernelGGL((gemm_f32_mfma<AL, BL, EPI, true>), grid, dim3(256), 0, s, a);
     else                    hipLaunchKernelGGL((gemm_f32_mfma<AL, BL, EPI, false>), grid, dim3(256), 0, s, a);
     return btvae::check_launch(what);
 }
@@ -413,6 +308,16 @@ int pick_splits(int tiles, int K, size_t ws_floats, size_t out_elems) {
 
 using namespace btvae;
 
+// Operand precision of the Linear-layer products (forward, dgrad, wgrad): 0 = fp32 MFMA (default), 1 = operands
+// rounded to bf16 on the way into LDS, fp32 accumulation.  Process-wide; products whose operands are not 16-byte
+// aligned with leading dimensions that are multiples of 4 stay on the fp32 kernel either way.
+BTVAE_API int btvae_set_gemm_precision(int mode) {
+    BTVAE_REQUIRE(mode == 0 || mode == 1, "set_gemm_precision: unknown mode %d (0 = fp32, 1 = bf16 operands)", mode);
+    g_precision.store(mode, std::memory_order_relaxed);
+    return 0;
+}
+BTVAE_API int btvae_get_gemm_precision(void) { return g_precision.load(std::memory_order_relaxed); }
+
 // Y = relu(X W^T + b), plus per-128-row-tile column (mean, M2) partials for BatchNorm statistics.
 BTVAE_API int btvae_linear_relu_stats_fwd(const float* X, int ldx, const float* W, const float* b, float* Y,
                                           float* stat_partials, int M, int K, int N, void* stream) {
@@ -420,7 +325,7 @@ BTVAE_API int btvae_linear_relu_stats_fwd(const float* X, int ldx, const float* 
     GemmArgs a{}; a.A = X; a.lda = ldx; a.B = W; a.ldb = K; a.C = Y; a.ldc = N; a.M = M; a.N = N; a.K = K;
     a.bias = b; a.stats = stat_partials;
     ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    return launch<LAY_K, LAY_K, EPI_RELU_STATS>(a, 1, (hipStream_t)stream, "linear_relu_stats_fwd");
+    return launch<LAY_K, LAY_K, EPI_RELU_STATS>(a, 1, (hipStream_t)stream, "linear_relu_stats_fwd", true);
 }
 
 // Out = relu(X W^T + b) * scale + shift (+ R): Linear+ReLU+eval-mode BatchNorm(+residual) in one pass.
@@ -430,7 +335,7 @@ BTVAE_API int btvae_linear_relu_affine_fwd(const float* X, int ldx, const float*
     GemmArgs a{}; a.A = X; a.lda = ldx; a.B = W; a.ldb = K; a.C = Out; a.ldc = N; a.M = M; a.N = N; a.K = K;
     a.bias = b; a.scale = scale; a.shift = shift; a.R = R; a.ldr = N;
     ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    return launch<LAY_K, LAY_K, EPI_RELU_AFFINE>(a, 1, (hipStream_t)stream, "linear_relu_affine_fwd");
+    return launch<LAY_K, LAY_K, EPI_RELU_AFFINE>(a, 1, (hipStream_t)stream, "linear_relu_affine_fwd", true);
 }
 
 // Head output layer: raw = X W^T + b; act 0: clamp, 1: clamp(softplus), 2: clamp(relu).
@@ -442,7 +347,7 @@ BTVAE_API int btvae_linear_head_fwd(const float* X, int ldx, const float* W, con
     GemmArgs a{}; a.A = X; a.lda = ldx; a.B = W; a.ldb = K; a.C = Out; a.ldc = N; a.M = M; a.N = N; a.K = K;
     a.bias = b; a.C2 = Dfac; a.C3 = Sq; a.act = act; a.lo = lo; a.hi = hi;
     ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    return launch<LAY_K, LAY_K, EPI_HEAD>(a, 1, (hipStream_t)stream, "linear_head_fwd");
+    return launch<LAY_K, LAY_K, EPI_HEAD>(a, 1, (hipStream_t)stream, "linear_head_fwd", true);
 }
 
 // dX[M,K] = dY[M,N] W[N,K] (+ R[M,K]).
@@ -450,7 +355,7 @@ BTVAE_API int btvae_linear_dgrad(const float* dY, const float* W, const float* R
     GemmArgs a{}; a.A = dY; a.lda = N; a.B = W; a.ldb = K; a.C = dX; a.ldc = lddx; a.M = M; a.N = K; a.K = N;
     a.R = R; a.ldr = lddx;
     ProfScope ps(PK_GEMM_DGRAD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * N + (double)N * K + (double)M * K));
-    return launch<LAY_K, LAY_M, EPI_PLAIN>(a, 1, (hipStream_t)stream, "linear_dgrad");
+    return launch<LAY_K, LAY_M, EPI_PLAIN>(a, 1, (hipStream_t)stream, "linear_dgrad", true);
 }
 
 // C[M,N] (+)= A^T B with A stored [K][M] (lda) and B stored [K][N] (ldb); the reduction is split over
@@ -463,16 +368,16 @@ BTVAE_API int btvae_matmul_tn(const float* A, int lda, const float* B, int ldb, 
     const size_t out_elems = (size_t)M * N;
     int splits = pick_splits(tiles, K, ws ? (size_t)ws_floats : 0, out_elems);
     ProfScope ps(prof_kind, s, 2.0 * M * N * K, 4.0 * ((double)K * M + (double)K * N + (double)M * N));
+    const bool reduced_ok = prof_kind == PK_GEMM_WGRAD;
     if (splits == 1 && !accumulate) {
         a.C = C;
-        return launch<LAY_M, LAY_M, EPI_PLAIN>(a, 1, s, "matmul_tn");
+        return launch<LAY_M, LAY_M, EPI_PLAIN>(a, 1, s, "matmul_tn", reduced_ok);
     }
     BTVAE_REQUIRE(ws && (size_t)ws_floats >= out_elems, "matmul_tn: workspace of %lld floats too small for %zu", ws_floats, out_elems);
     a.C = ws; a.slab_stride = out_elems;
-    int rc = launch<LAY_M, LAY_M, EPI_PLAIN>(a, splits, s, "matmul_tn");
+    int rc = launch<LAY_M, LAY_M, EPI_PLAIN>(a, splits, s, "matmul_tn", reduced_ok);
     if (rc) return rc;
-    const int kchunk = (((K + splits - 1) / splits) + BK - 1) / BK * BK;
-    const int nslab = (K + kchunk - 1) / kchunk;
+    const int nslab = (K + a.kchunk - 1) / a.kchunk;
     const int blocks = (int)std::min<size_t>((out_elems + 255) / 256, 2048);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, C, out_elems, nslab, out_elems, accumulate);
     return check_launch("matmul_tn.reduce");

@@ -1,0 +1,165 @@
+// Pieces shared by the fp32 and bf16 MFMA GEMM kernels: argument block, operand-layout / epilogue tags and the
+// epilogue itself.  Both kernels produce the same accumulator image (2x2 MFMA tiles of 32x32 per wave, element r
+// of a tile = row (r&3)+8(r>>2)+4*(lane>>5), column lane&31), so one epilogue serves both.
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace btvae_gemm {
+
+constexpr int BM = 128, BN = 128;
+
+enum { LAY_K = 0, LAY_M = 1 };
+enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_RELU_STATS = 2, EPI_RELU_AFFINE = 3, EPI_HEAD = 4, EPI_MUL = 5 };
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    int lda, ldb, ldc;
+    int M, N, K;
+    int kchunk;                 // reduction elements per blockIdx.z (multiple of BK)
+    size_t slab_stride;         // C elements between z slabs
+    const float* bias;          // [N]
+    const float* scale; const float* shift;   // [N]  (EPI_RELU_AFFINE; null = identity)
+    const float* R; int ldr;    // add-in [M,N]       (EPI_PLAIN / EPI_RELU_AFFINE; null = none)
+    float* C2; float* C3;       // EPI_HEAD: derivative factor, squared value (either may be null)
+    float* stats;               // EPI_RELU_STATS: [tiles_m][2][N] = per-tile column (mean, M2)
+    const float* E1; const float* E2; int lde;  // EPI_MUL
+    int act; float lo, hi;      // EPI_HEAD
+    int a_vec, b_vec;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float softplus5(float x) { return x > 5.f ? x : log1pf(expf(x)); }
+
+// `red` is LDS scratch of at least 6*128 floats that no wave still reads as a tile.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2][2], float* red, int m0, int n0, int tile_m) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    // ---- epilogue: accumulator element r of tile (rb,cb) is row (r&3)+8(r>>2)+4*lh, column li ----
+    float colv[2][3];   // per-column vectors: bias / scale / shift
+    int colg[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int col = n0 + wc * 64 + cb * 32 + li;
+        colg[cb] = col;
+        const bool ok = col < p.N;
+        colv[cb][0] = (EPI == EPI_BIAS || EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE || EPI == EPI_HEAD) && ok && p.bias ? p.bias[col] : 0.f;
+        colv[cb][1] = (EPI == EPI_RELU_AFFINE && ok && p.scale) ? p.scale[col] : 1.f;
+        colv[cb][2] = (EPI == EPI_RELU_AFFINE && ok && p.shift) ? p.shift[col] : 0.f;
+    }
+    float* Cz = p.C + (size_t)blockIdx.z * p.slab_stride;
+
+    float st_n[2], st_mean[2], st_m2[2];   // EPI_RELU_STATS: this lane's (count, mean, M2) per column block
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int col = colg[cb];
+        float shiftK = 0.f, s = 0.f, q = 0.f, cnt = 0.f;
+        bool have = false;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const bool ok = row < p.M && col < p.N;
+                float v = acc[rb][cb][r];
+                if (EPI == EPI_PLAIN) {
+                    if (ok) {
+                        if (p.R) v += p.R[(size_t)row * p.ldr + col];
+                        Cz[(size_t)row * p.ldc + col] = v;
+                    }
+                } else if (EPI == EPI_BIAS) {
+                    if (ok) {
+                        v += colv[cb][0];
+                        if (p.R) v += p.R[(size_t)row * p.ldr + col];
+                        Cz[(size_t)row * p.ldc + col] = v;
+                    }
+                } else if (EPI == EPI_RELU_STATS) {
+                    v = fmaxf(v + colv[cb][0], 0.f);
+                    if (ok) {
+                        Cz[(size_t)row * p.ldc + col] = v;
+                        if (!have) { shiftK = v; have = true; }
+                        const float d = v - shiftK;
+                        s += d; q += d * d; cnt += 1.f;
+                    }
+                } else if (EPI == EPI_RELU_AFFINE) {
+                    v = fmaxf(v + colv[cb][0], 0.f) * colv[cb][1] + colv[cb][2];
+                    if (ok) {
+                        if (p.R) v += p.R[(size_t)row * p.ldr + col];
+                        Cz[(size_t)row * p.ldc + col] = v;
+                    }
+                } else if (EPI == EPI_HEAD) {
+                    const float raw = v + colv[cb][0];
+                    float val, df;
+                    if (p.act == 0) {            // clamp
+                        val = fminf(fmaxf(raw, p.lo), p.hi);
+                        df = (raw >= p.lo && raw <= p.hi) ? 1.f : 0.f;
+                    } else if (p.act == 1) {     // clamp(softplus(raw; threshold 5))
+                        const float sp = softplus5(raw);
+                        val = fminf(fmaxf(sp, p.lo), p.hi);
+                        df = (sp >= p.lo && sp <= p.hi) ? (raw > 5.f ? 1.f : 1.f / (1.f + expf(-raw))) : 0.f;
+                    } else {                     // clamp(relu(raw))
+                        const float rl = fmaxf(raw, 0.f);
+                        val = fminf(fmaxf(rl, p.lo), p.hi);
+                        df = (raw > 0.f && rl >= p.lo && rl <= p.hi) ? 1.f : 0.f;
+                    }
+                    if (ok) {
+                        const size_t o = (size_t)row * p.ldc + col;
+                        Cz[o] = val;
+                        if (p.C2) p.C2[o] = df;
+                        if (p.C3) p.C3[o] = val * val;
+                    }
+                } else if (EPI == EPI_MUL) {
+                    if (ok) {
+                        const size_t e = (size_t)row * p.lde + col;
+                        Cz[(size_t)row * p.ldc + col] = v * p.E1[e] * p.E2[e];
+                    }
+                }
+            }
+        }
+        if (EPI == EPI_RELU_STATS) {
+            float mean = 0.f, m2 = 0.f;
+            if (cnt > 0.f) { mean = shiftK + s / cnt; m2 = fmaxf(q - s * s / cnt, 0.f); }
+            // merge the two lane halves (rows +4): Chan's pairwise update
+            const float on = __shfl_xor(cnt, 32, 64), om = __shfl_xor(mean, 32, 64), o2 = __shfl_xor(m2, 32, 64);
+            const float n = cnt + on;
+            if (n > 0.f) {
+                const float dlt = om - mean;
+                m2 = m2 + o2 + dlt * dlt * (cnt * on / n);
+                mean = (cnt * mean + on * om) / n;
+            }
+            st_n[cb] = n; st_mean[cb] = mean; st_m2[cb] = m2;
+        }
+    }
+
+    if (EPI == EPI_RELU_STATS) {
+        // red = [wr][3][128]
+        if (lh == 0) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int c = wc * 64 + cb * 32 + li;
+                red[(wr * 3 + 0) * 128 + c] = st_n[cb];
+                red[(wr * 3 + 1) * 128 + c] = st_mean[cb];
+                red[(wr * 3 + 2) * 128 + c] = st_m2[cb];
+            }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            const float na = red[0 * 128 + tid], ma = red[1 * 128 + tid], qa = red[2 * 128 + tid];
+            const float nb = red[3 * 128 + tid], mb = red[4 * 128 + tid], qb = red[5 * 128 + tid];
+            const float n = na + nb;
+            float mean = ma, m2 = qa;
+            if (nb > 0.f) {
+                const float dlt = mb - ma;
+                m2 = qa + qb + dlt * dlt * (na * nb / n);
+                mean = (na * ma + nb * mb) / n;
+            }
+            p.stats[((size_t)tile_m * 2 + 0) * p.N + n0 + tid] = mean;
+            p.stats[((size_t)tile_m * 2 + 1) * p.N + n0 + tid] = m2;
+        }
+    }
+}
+
+}  // namespace btvae_gemm

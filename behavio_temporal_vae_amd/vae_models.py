@@ -133,7 +133,16 @@ class VAE(torch.nn.Module):
         self._arena = None
         self._grad_arena = None
         self._dp_world = 1
+        # operand precision of the Linear products: "fp32" (the reference's arithmetic) or "bf16"; an extra
+        # keyword of the model config, swallowed by the reference's constructors like any other unknown key
+        self.gemm_precision = "fp32"
+        self.set_gemm_precision(_.get("gemm_precision", "fp32"))
         self._finish_init()
+
+    def set_gemm_precision(self, name: str):
+        if name not in nv.GEMM_PRECISIONS:
+            raise ValueError(f"unknown gemm_precision {name!r}; choose from {sorted(nv.GEMM_PRECISIONS)}")
+        self.gemm_precision = name
 
     # ------------------------------------------------------------------ arenas
     def _finish_init(self):
@@ -179,6 +188,11 @@ class VAE(torch.nn.Module):
         if p0.data_ptr() != self._arena.data_ptr() or p0.grad is None:
             self._build_arena()
         nv.ensure_device(self._arena.device)
+        self._sync_precision()
+
+    def _sync_precision(self):
+        if nv.get_gemm_precision() != self.gemm_precision:
+            nv.set_gemm_precision(self.gemm_precision)
 
     def _flush_bn_counters(self):
         for net in (self.encoder, self.decoder):
@@ -287,6 +301,7 @@ class VAE(torch.nn.Module):
     def _loss_and_backward(self, fw: _Fwd, x, beta: float) -> torch.Tensor:
         """ELBO scalars plus all parameter gradients of ``loss = -(rll - beta*kl)`` into the gradient arena."""
         x = self._prep(x, "inputs")
+        self._sync_precision()
         rows = fw.S * fw.B
         g = -1.0 / rows
         dec = self.decoder
@@ -529,6 +544,8 @@ class CVAE(VAE):
         self._arena = None
         self._grad_arena = None
         self._dp_world = 1
+        self.gemm_precision = "fp32"
+        self.set_gemm_precision(_.get("gemm_precision", "fp32"))
         self._finish_init()
 
     def forward(self, inputs, conditions, num_mc_samples=1):

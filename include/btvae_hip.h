@@ -22,6 +22,14 @@ int btvae_init(int device);
  * 6 reduce, 7 optim); collect after a device synchronisation into arrays of 8. */
 int btvae_prof_enable(int on);
 int btvae_prof_collect(double* ms, double* flops, double* bytes, long long* launches, int n);
+/* Before btvae_prof_collect: the launches of one family with the largest FLOP count (its dominant shape). */
+int btvae_prof_dominant(int kind, double* ms, double* flops_per_launch, long long* count);
+
+/* Operand precision of the Linear-layer products (btvae_linear_*_fwd, _dgrad, _wgrad): 0 = fp32 MFMA (default,
+ * the precision torch.nn.Linear runs at in the reference, src/submodels.py:15-17), 1 = operands rounded to bf16
+ * on the way into LDS with fp32 accumulation.  Process-wide.  The covariance products stay fp32. */
+int btvae_set_gemm_precision(int mode);
+int btvae_get_gemm_precision(void);
 
 /* ---- Linear layers on MFMA (src/submodels.py:15-17 Linear+ReLU, :20-21 BatchNorm1d, :28-35 NNBlock.forward) ---- */
 /* Y[M,N] = relu(X[M,K] W[N,K]^T + b); stat_partials[ceil(M/128)][2][N] = per-row-tile column (mean, M2). */

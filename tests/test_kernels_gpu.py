@@ -354,3 +354,39 @@ def test_cond_mvn(dev):
     o = torch.empty(rows, device=dev)
     nv.call("btvae_lse_over_k", P(lp), P(o), 7, rows)
     close(o, torch.logsumexp(lp.cpu().double(), 0) - math.log(7), 1e-6, 1e-5, "lse over k")
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 136), (128, 128, 32), (1000, 48, 1000), (257, 100, 52)])
+def test_linear_products_bf16_operands(dev, M, N, K):
+    """bf16-operand mode of the Linear products: equals the fp64 product of the bf16-rounded operands (fp32
+    accumulation error only), for forward (+bias, ReLU, column statistics), dgrad (+add-in) and split wgrad."""
+    g = torch.Generator().manual_seed(M + N + K)
+    X = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) * 0.1; b = torch.randn(N, generator=g)
+    dY = torch.randn(M, N, generator=g); R = torch.randn(M, K, generator=g)
+    rb = lambda t: t.to(torch.bfloat16).double()
+    Xd, Wd, bd, dYd, Rd = (t.to(dev) for t in (X, W, b, dY, R))
+    tiles = (M + 127) // 128
+    Y = torch.empty(M, N, device=dev); part = torch.empty(tiles, 2, N, device=dev)
+    dX = torch.empty(M, K, device=dev); dW = torch.empty(N, K, device=dev)
+    ws = torch.empty(4 * 1024 * 1024, device=dev)
+    nv.set_gemm_precision("bf16")
+    try:
+        assert nv.get_gemm_precision() == "bf16"
+        nv.call("btvae_linear_relu_stats_fwd", P(Xd), K, P(Wd), P(bd), P(Y), P(part), M, K, N)
+        nv.call("btvae_linear_dgrad", P(dYd), P(Wd), P(Rd), P(dX), K, M, N, K)
+        nv.call("btvae_linear_wgrad", P(dYd), P(Xd), K, P(dW), P(ws), ws.numel(), M, N, K, 0)
+        torch.cuda.synchronize()
+    finally:
+        nv.set_gemm_precision("fp32")
+    ref_y = torch.relu(rb(X) @ rb(W).t() + b.double())
+    assert (Y.cpu().double() - ref_y).abs().max() <= 2e-5 * max(1.0, ref_y.abs().max().item())
+    ref_dx = rb(dY) @ rb(W) + R.double()
+    assert (dX.cpu().double() - ref_dx).abs().max() <= 2e-5 * ref_dx.abs().max().item()
+    ref_dw = rb(dY).t() @ rb(X)
+    assert (dW.cpu().double() - ref_dw).abs().max() <= 2e-5 * ref_dw.abs().max().item()
+    # column statistics partials describe the Y that was written
+    yy = Y.cpu().double()
+    for t in range(tiles):
+        blk = yy[t * 128:(t + 1) * 128]
+        assert torch.allclose(part[t, 0].cpu().double(), blk.mean(0), rtol=1e-4, atol=1e-5)
+        assert torch.allclose(part[t, 1].cpu().double(), ((blk - blk.mean(0)) ** 2).sum(0), rtol=1e-3, atol=1e-4)

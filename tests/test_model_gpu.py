@@ -251,3 +251,56 @@ def test_train_core_against_oracle_random_shapes(dev):
         loss = m._train_step(x.to(dev), c.to(dev), opt, eps=eps.to(dev))
         got = [loss[k].item() for k in ("loss", "elbo", "rll", "kl")]
         assert rel_err(got, [ref[k] for k in ("loss", "elbo", "rll", "kl")]) < 1e-4, (t, got, ref)
+
+
+def test_wide_conditioning_3d_fp32_and_bf16(dev):
+    """Sweep-style shape (scripts/config_sweep.py:76-81): months + weekdays + day-before profile + T=500 user topics
+    -> C = 528, D = L = 24, sampled (3-D) conditions [B, S, C].  fp32 MFMA path vs the fp32 oracle at 1e-4; the
+    bf16-operand path at 1e-2 on every ELBO term (forward, eval and train mode) and on a three-step loss trajectory."""
+    from oracle import refimpl as R
+    from behavio_temporal_vae_amd.vae_models import CVAE
+    H = 200
+    cfg = {"latent_dim": 24, "distribution_dict": {
+        "posterior": {"dist_type": "normal", "sigma_lim": 0.05, "mu_upper_lim": 5.0, "mu_lower_lim": -5.0, "num_neurons": H,
+                      "num_hidden_layers": 2, "dropout": False, "batch_normalization": True},
+        "likelihood": {"dist_type": "dict-gauss", "vocab_size": 100, "sigma_lim": 1e-4, "marginal_std_lim": 0.1, "mu_lower_lim": -3,
+                       "num_neurons": H, "num_hidden_layers": 2, "dropout": False, "batch_normalization": True}}}
+    D, C, B, S = 24, 528, 192, 4
+    torch.manual_seed(11)
+    m = CVAE(input_dim=D, conditioner=Cdim(C), **cfg)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    spec = R.model_spec(D, C, cfg)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B, D, generator=gen).clamp(-3, 5)
+    topics = torch.distributions.Dirichlet(torch.full((500,), 0.05)).sample((B, S))
+    c = torch.cat([torch.randn(B, S, 28, generator=gen), topics], -1).float()
+    eps = torch.randn(S, B, 24, generator=gen)
+    m = m.to(dev)
+    for train in (True, False):
+        lik, post, _ = R.cvae_forward(dict(sd), spec, x, c, eps, train, {})
+        ref = {k: float(v) for k, v in R.elbo_terms(sd, spec, x, lik, post, beta=1.0).items()}
+        for prec, tol in (("fp32", 1e-4), ("bf16", 1e-2)):
+            m.load_state_dict(sd)
+            m.train() if train else m.eval()
+            m.set_gemm_precision(prec)
+            fw = m._run_forward(x.to(dev), c.to(dev), S, eps=eps.to(dev))
+            got = m._loss_from_forward(fw, x.to(dev), 1.0).tolist()
+            for v, k in zip(got, ("loss", "elbo", "rll", "kl")):
+                assert abs(v - ref[k]) <= tol * abs(ref[k]) + tol * 1e-1, (train, prec, k, v, ref[k])
+    # training (2-D conditions, as train_core feeds them) in bf16 follows the fp32 oracle's loss trajectory to 1e-2
+    c2 = c[:, 0].contiguous()
+    m.load_state_dict(sd)
+    m.train()
+    m.set_gemm_precision("bf16")
+    m.train_kwargs = {"num_mc_samples": S, "beta": 1.0, "gradient_clipping": True, "gradient_clipping_kwargs": {"max_norm": 1.0}}
+    opt = m.get_optimizer(lr=1e-3, weight_decay=1e-5)
+    st = R.AdamState()
+    sdo = {k: v.clone() for k, v in sd.items()}
+    for t in range(3):
+        ref, _, _ = R.train_step(sdo, spec, st, x, c2, eps, lr=1e-3, weight_decay=1e-5, beta=1.0, max_norm=1.0)
+        loss = m._train_step(x.to(dev), c2.to(dev), opt, eps=eps.to(dev))
+        got = [loss[k].item() for k in ("loss", "elbo", "rll", "kl")]
+        assert rel_err(got, [ref[k] for k in ("loss", "elbo", "rll", "kl")]) < 1e-2, (t, got, ref)
+    m.set_gemm_precision("fp32")
+    from behavio_temporal_vae_amd import _native as nv
+    nv.set_gemm_precision("fp32")

@@ -18,7 +18,10 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     dev = torch.device("cuda:0")
     nv.ensure_device(dev)
-    M, N, K = 65536, 1000, 1000
+    if os.environ.get("BTVAE_BENCH_BF16"):
+        nv.set_gemm_precision("bf16")
+    M = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+    N = K = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
     g = torch.Generator(device=dev).manual_seed(0)
     X = torch.randn(M, K, device=dev, generator=g)
     W = torch.randn(N, K, device=dev, generator=g) * 0.03

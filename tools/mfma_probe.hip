@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ G, flo
     for (int i = 0; i < 2; ++i) { a0[i] = make_float4(1, 2, 3, 4); b0[i] = a0[i]; a1[i] = a0[i]; b1[i] = a0[i]; }
     float4 sa[NQ], sb[NQ];
     const float* gp = G + (size_t)blockIdx.x * 128 * ld;
+    const float* gb = G + (size_t)(MODE & 8 ? (blockIdx.x & 7) : 0) * 128 * ld;   // MODE&8: eight distinct B tiles as in the real GEMM
     auto mma = [&](const float4 (&ag)[2], const float4 (&bg)[2]) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ G, flo
                 const int f = tid + 256 * q;
                 const int r = f / (BK / 4), c = (f % (BK / 4)) * 4;
                 sa[q] = *reinterpret_cast<const float4*>(gp + (size_t)r * ld + t * BK + c);
-                sb[q] = *reinterpret_cast<const float4*>(G + (size_t)r * ld + t * BK + c);
+                sb[q] = *reinterpret_cast<const float4*>(gb + (size_t)r * ld + t * BK + c);
             }
         }
         const float* As = smem[cur][0];
@@ -111,6 +112,7 @@ int main() {
         run<7, 1, 32>("BK32 1 LDS buffer (3 blocks/CU fit)", G, out, blocks, tiles, ld);
         run<7, 1, 64>("BK64 1 LDS buffer (2 blocks/CU)", G, out, blocks, tiles, ld);
         run<7, 2, 16>("BK16 2 LDS buffers (3 blocks/CU fit)", G, out, blocks, tiles, ld);
+        run<15, 2, 16>("BK16 2 LDS buffers, 8 distinct B tiles", G, out, blocks, tiles, ld);
     }
     return 0;
 }
