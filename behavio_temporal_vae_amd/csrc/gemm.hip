@@ -31,6 +31,14 @@ constexpr int LDM = 128 + 4;            // row stride of an m/n-contiguous LDS t
 constexpr int TILE_FLOATS = (128 * LDK > BK * LDM) ? 128 * LDK : BK * LDM;
 constexpr int KC4 = BK / 4;             // 16-byte chunks per row of a k-contiguous tile
 
+// Row of a k-contiguous tile that staging slot f (one 16-byte chunk) belongs to.  With 4 chunks per row an 8-lane
+// LDS store group spans two rows; taking them 4 rows apart puts them in different halves of the 32 store banks
+// (adjacent rows, 80 B apart, would collide on 4 banks).
+__device__ __forceinline__ int krow(int f) {
+    const int rr = f / KC4;
+    return KC4 == 4 ? ((rr & ~5) | ((rr & 1) << 2) | ((rr >> 2) & 1)) : rr;
+}
+
 
 
 // Vector path (rows 16-byte aligned, contiguous extent and leading dimension multiples of 4): one predicated
@@ -45,7 +53,7 @@ __device__ __forceinline__ void g2r_vec(const float* __restrict__ P, int ld, int
         bool ok;
         size_t off;
         if (LAY == LAY_K) {
-            const int gr = row0 + f / KC4, gk = k0 + ((f % KC4) << 2);
+            const int gr = row0 + krow(f), gk = k0 + ((f % KC4) << 2);
             ok = gr < nrows && gk + 3 < kend;
             off = (size_t)gr * ld + gk;
         } else {
@@ -69,7 +77,7 @@ __device__ __forceinline__ void g2r_vec_full(const float* __restrict__ P, int ld
     for (int q = 0; q < NQ; ++q) {
         const int f = tid + 256 * q;
         size_t off;
-        if (LAY == LAY_K) off = (size_t)min(row0 + f / KC4, nrows - 1) * ld + (k0 + ((f % KC4) << 2));
+        if (LAY == LAY_K) off = (size_t)min(row0 + krow(f), nrows - 1) * ld + (k0 + ((f % KC4) << 2));
         else              off = (size_t)(k0 + (f >> 5)) * ld + min(row0 + ((f & 31) << 2), nrows - 4);
         st[q] = *reinterpret_cast<const float4*>(P + off);
     }
@@ -85,7 +93,7 @@ __device__ __forceinline__ void g2r(const float* __restrict__ P, int ld, int row
         const int f = tid + 256 * q;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (LAY == LAY_K) {
-            const int r = f / KC4, c = (f % KC4) << 2;
+            const int r = krow(f), c = (f % KC4) << 2;
             const int gr = row0 + r, gk = k0 + c;
             if (gr < nrows && gk < kend) {
                 const float* src = P + (size_t)gr * ld + gk;
@@ -120,7 +128,7 @@ __device__ __forceinline__ void r2s(float* S, int tid, const float4 (&st)[NQ]) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int f = tid + 256 * q;
-        if (LAY == LAY_K) *reinterpret_cast<float4*>(S + (f / KC4) * LDK + ((f % KC4) << 2)) = st[q];
+        if (LAY == LAY_K) *reinterpret_cast<float4*>(S + krow(f) * LDK + ((f % KC4) << 2)) = st[q];
         else              *reinterpret_cast<float4*>(S + (f >> 5) * LDM + ((f & 31) << 2)) = st[q];
     }
 }

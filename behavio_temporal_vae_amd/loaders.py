@@ -2,7 +2,8 @@
 
 The reference feeds training through a DataLoader whose dataset encodes the conditions of ONE item per call
 in 8 worker processes (scripts/training.py:17, src/datasets.py:20-23).  Here conditions are encoded once for the
-whole set, inputs and conditions live on the GPU, and a batch is an index gather on the device.  The shuffled
+whole set, inputs and conditions live on the GPU, and a batch is an index gather on the device (sampled Dirichlet
+conditions are drawn there too, ``datasets.DeviceConditionEncoder``).  The shuffled
 index stream is generated exactly like ``RandomSampler`` does it (a seed drawn from the default torch
 generator, then ``randperm`` from a generator with that seed), so a given ``torch.manual_seed`` yields the same
 batches as the reference.  Under data parallelism every rank walks the same global stream and takes its
@@ -32,9 +33,8 @@ class DeviceBatchLoader:
         cond = dataset.conditioner
         self.random = cond.is_random() if hasattr(cond, "is_random") else False
         self.x = torch.from_numpy(np.ascontiguousarray(dataset.inputs, dtype=np.float32)).to(device)
-        self.c = None
-        if not self.random:
-            self.c = torch.from_numpy(np.asarray(cond.transform(dataset.conditions), dtype=np.float32)).to(device)
+        from .datasets import DeviceConditionEncoder
+        self.enc = DeviceConditionEncoder(cond, dataset.conditions, device)
 
     def __len__(self):
         n, gb = len(self.dataset), self.batch_sampler.batch_size * self.world
@@ -64,10 +64,4 @@ class DeviceBatchLoader:
             idx = glob[b:e]
             idx_d = idx.to(self.device)
             x = self.x.index_select(0, idx_d)
-            if self.random:
-                raw = {k: v[idx.numpy()] for k, v in self.dataset.conditions.items()}
-                c = np.asarray(self.dataset.conditioner.transform(raw, num_samples=self.dataset.num_samples), dtype=np.float32)
-                c = torch.from_numpy(np.ascontiguousarray(c.transpose(1, 0, 2))).to(self.device)
-            else:
-                c = self.c.index_select(0, idx_d)
-            yield x, c
+            yield x, self.enc.encode(idx_d, self.dataset.num_samples)

@@ -142,6 +142,13 @@ int btvae_masked_scatter(float* dst, const long long* idx, const float* src, lon
 int btvae_lse_over_k(const float* logp, float* out, int K, int B, void* stream);
 int btvae_pack_lower(const float* full, float* packed, long long rows, int D, void* stream);
 
+/* ---- condition feed ---- */
+/* Dirichlet draws of DirichletTransformer.transform(style "sample") (src/utils.py:112-129: gamma(alpha,1) draws
+ * normalised per row) made on the device and written into the [B, S, ldo] condition tensor at column col0:
+ * out[(b*S+s)*ldo + col0 + t], alpha = gamma[rows[b]*T + t] (rows NULL: b).  Philox(seed, offset..offset+63). */
+int btvae_dirichlet_sample(const float* gamma, const long long* rows, float* out, int B, int S, int T, int ldo,
+                           int col0, unsigned long long seed, unsigned long long offset, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

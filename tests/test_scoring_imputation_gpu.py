@@ -230,3 +230,49 @@ def test_training_entry_point_synthetic(dev, tmp_path):
     assert all(torch.equal(v, m2.state_dict()[k]) for k, v in sd.items())
     mk = json.load(open(os.path.join(run, "model_kwargs.json")))
     assert set(mk) == {"latent_dim", "distribution_dict", "_"}
+
+
+def test_device_condition_feed_dirichlet(dev):
+    """Sampled (Dirichlet "sample" style) conditions drawn on the device.  The deterministic tags' columns equal the
+    host conditioner bit for bit; the sampled block is a Dirichlet(gamma) draw -- rows sum to 1, means and variances
+    match the closed forms, draws are reproducible under torch.manual_seed and differ call to call.  Parity with the
+    reference's numpy stream is unpinned by construction (different generator); the check is distributional."""
+    from behavio_temporal_vae_amd.conditioning_lib import Conditioner
+    from behavio_temporal_vae_amd.datasets import ConditionedDataset, DeviceConditionEncoder
+    from behavio_temporal_vae_amd.loaders import DeviceBatchLoader
+    rng = np.random.default_rng(0)
+    n, T, S = 64, 37, 4000
+    months = rng.integers(1, 13, size=(n, 1)); weekdays = rng.integers(0, 7, size=(n, 1))
+    day_before = rng.normal(size=(n, 3))
+    gammas = np.where(rng.random((n, T)) < 0.5, 0.01, 0.01 + rng.gamma(2.0, 3.0, size=(n, T)))   # sparse LDA-like rows
+    cset = {"months": months, "weekdays": weekdays, "users": gammas, "day_befores": day_before}
+    cond = Conditioner(tags=["months", "weekdays", "users", "day_befores"],
+                       supports=[list(range(1, 13)), list(range(7)), [0.01, 50.0], [-3, 3]],
+                       types=["circ", "circ", "dir", "identity"], condition_set=cset)
+    assert cond.is_random() and cond.cond_dim == 4 + T + 3
+    enc = DeviceConditionEncoder(cond, cset, dev)
+    idx = torch.tensor([5, 0, 63, 17], device=dev)
+    torch.manual_seed(7)
+    c = enc.encode(idx, S)
+    assert c.shape == (4, S, cond.cond_dim)
+    host = cond.transform({k: v[idx.cpu().numpy()] for k, v in cset.items()}, num_samples=2)   # [2, 4, C]
+    det = np.r_[0:4, 4 + T:4 + T + 3]
+    got = c.cpu().numpy()
+    assert np.array_equal(got[:, 0][:, det], host[0][:, det].astype(np.float32))
+    assert np.array_equal(got[:, -1][:, det], host[0][:, det].astype(np.float32))
+    d = got[:, :, 4:4 + T].astype(np.float64)
+    assert np.all(d >= 0) and np.allclose(d.sum(-1), 1.0, atol=1e-5)
+    g = gammas[idx.cpu().numpy()]
+    a0 = g.sum(1, keepdims=True)
+    mean, var = g / a0, g * (a0 - g) / (a0 ** 2 * (a0 + 1))
+    assert np.abs(d.mean(1) - mean).max() < 6 * np.sqrt(var.max() / S) + 1e-4
+    big = var > 1e-5
+    assert np.abs(d.var(1)[big] / var[big] - 1).max() < 0.2
+    enc2 = DeviceConditionEncoder(cond, cset, dev)
+    torch.manual_seed(7)
+    assert torch.equal(enc2.encode(idx, S), c)                       # same seed, same call number
+    assert not torch.equal(enc2.encode(idx, S)[..., 4:4 + T], c[..., 4:4 + T])
+    # the loader hands [B, S, C] batches to a model whose forward takes 3-D conditions
+    ds = ConditionedDataset(rng.normal(size=(n, 6)).astype(np.float32), cset, cond, num_samples=3)
+    x, cb = next(iter(DeviceBatchLoader(ds, 16, shuffle=True, drop_last=True, device=dev)))
+    assert x.shape == (16, 6) and cb.shape == (16, 3, cond.cond_dim) and cb.is_cuda
