@@ -14,6 +14,7 @@ import torch
 
 from . import _native as nv
 from . import engine as E
+from .autograd_ops import apply_net, dict_log_likelihood
 from .utils import kl_divergence, log_prob, matrix_normalizer  # noqa: F401  (re-exported like the reference does)
 
 ACTIVATION = torch.nn.ReLU()
@@ -99,6 +100,11 @@ class ParameterizerNN(torch.nn.Module):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
 
 
+def _wants_graph(dist) -> bool:
+    """An autograd graph is built only for a training-mode network that belongs to a model arena, under grad mode."""
+    return torch.is_grad_enabled() and dist.training and getattr(dist, "_arena_owner", None) is not None
+
+
 def _rows(t: torch.Tensor, width: int) -> torch.Tensor:
     nv.ensure_device(t.device)
     return nv.f32(t, "input").reshape(-1, width)
@@ -162,7 +168,10 @@ class GaussianNN(torch.nn.Module):
 
     def forward(self, inputs):
         x = _rows(inputs, self.input_dim)
-        out, _ = E.net_forward(self.plan(), x, self.training, None, self.head_specs())
+        if _wants_graph(self):
+            out = apply_net(self, x)
+        else:
+            out, _ = E.net_forward(self.plan(), x, self.training, None, self.head_specs())
         if not self.learn_sigma:
             out["sigma"] = torch.full_like(out["mu"], float(self.sigma_fixed))
         return out
@@ -171,6 +180,8 @@ class GaussianNN(torch.nn.Module):
         mu, sigma = param_dict["mu"], param_dict["sigma"]
         shape = torch.broadcast_shapes(mu.shape, sigma.shape)
         eps = torch.randn((num_samples, *shape), device=mu.device)
+        if torch.is_grad_enabled() and (mu.requires_grad or sigma.requires_grad):
+            return mu + sigma * eps          # keeps the graph; same arithmetic as the kernel
         L = shape[-1]
         mu_r, sg_r = mu.expand(shape).reshape(-1, L).contiguous(), sigma.expand(shape).reshape(-1, L).contiguous()
         nv.ensure_device(mu_r.device)
@@ -181,6 +192,8 @@ class GaussianNN(torch.nn.Module):
         return self.rsample(param_dict=param_dict, num_samples=num_samples)
 
     def log_likelihood(self, targets, param_dict=None):
+        if torch.is_grad_enabled() and (param_dict["mu"].requires_grad or param_dict["sigma"].requires_grad):
+            return log_prob("Normal", param_dict, targets).sum(dim=-1)
         x_r, mu_r, sg_r, lead, _ = _expand_pair(targets, param_dict["mu"], param_dict["sigma"])
         nv.ensure_device(mu_r.device)
         logp, _, _ = E.diag_loglik(nv.f32(x_r), nv.f32(mu_r), nv.f32(sg_r))
@@ -241,11 +254,13 @@ class DictionaryGaussian(torch.nn.Module):
 
     def forward(self, inputs):
         x = _rows(inputs, self.input_dim)
+        if _wants_graph(self):
+            return apply_net(self, x)
         out, _ = E.net_forward(self.plan(), x, self.training, None, self.head_specs())
         return out
 
     def rsample(self, param_dict=None, num_samples=1, **_):
-        mu, sigma = param_dict["mu"], param_dict["sigma"]
+        mu, sigma = param_dict["mu"].detach(), param_dict["sigma"].detach()
         eps = torch.randn((num_samples, *sigma.shape), device=sigma.device)
         scaled = (eps * sigma).reshape(-1, self.vocab_size).contiguous()
         rows = scaled.shape[0]
@@ -266,6 +281,8 @@ class DictionaryGaussian(torch.nn.Module):
         mu_r = mu.expand(*lead, D).reshape(-1, D).contiguous()
         sg_r = sigma.expand(*lead, V).reshape(-1, V).contiguous()
         x_r, _, _, _, B = _expand_pair(targets, mu.expand(*lead, D), mu.expand(*lead, D))
+        if torch.is_grad_enabled() and (mu.requires_grad or sigma.requires_grad):
+            return dict_log_likelihood(self, nv.f32(x_r.detach()), mu_r, sg_r).view(lead)
         logp = E.dict_loglik_fwd(self.tables(), nv.f32(x_r), nv.f32(mu_r), (sg_r * sg_r).contiguous())
         return logp.view(lead)
 

@@ -12,6 +12,7 @@ from __future__ import annotations
 import datetime
 import json
 import os
+import weakref
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -174,6 +175,19 @@ class VAE(torch.nn.Module):
                 p.data = arena[o:o + p.numel()].view(p.shape)
                 p.grad = grads[o:o + p.numel()].view(p.shape)
         self._arena, self._grad_arena, self._enc_span = arena, grads, enc_span
+        self._offsets = offs
+        ref = weakref.ref(self)
+        for net in (self.encoder, self.decoder):
+            object.__setattr__(net, "_arena_owner", ref)
+
+    def _reattach_grads(self):
+        """Give parameters whose ``.grad`` is None (a stock optimizer's ``zero_grad(set_to_none=True)``) their
+        view of the gradient arena back, zeroed."""
+        for p, o in zip(self._arena_params(), self._offsets):
+            if p.grad is None:
+                seg = self._grad_arena[o:o + p.numel()]
+                seg.zero_()
+                p.grad = seg.view(p.shape)
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -266,7 +280,43 @@ class VAE(torch.nn.Module):
         z = fw.zc.view(S, B, -1)[..., :L]
         return {"params": lik}, {"params": post, "samples": z}
 
+    def _graph_mode(self) -> bool:
+        """Module-level ``forward``/``loss`` build an autograd graph only in train mode under grad mode."""
+        return torch.is_grad_enabled() and self.training
+
+    def _forward_graph(self, x, c, S: int):
+        """``forward`` with autograd nodes attached (src/vae_models.py:260-280): encoder network, z = mu + sigma*eps,
+        decoder network.  Same kernels as the fused path; the glue between them is ordinary torch arithmetic."""
+        self._check_arena()
+        x = self._prep(x, "inputs")
+        B, L = x.shape[0], self.latent_dim
+        if c is None:
+            post = self.encoder(x)
+            z = self.encoder.rsample(post, num_samples=S)
+            dec_in = z
+        elif c.ndim == 2:
+            c = self._prep(c, "conditions")
+            post = self.encoder(torch.cat((x, c), dim=-1))
+            z = self.encoder.rsample(post, num_samples=S)
+            dec_in = torch.cat((z, c.unsqueeze(0).expand(S, B, c.shape[-1])), dim=2)
+        elif c.ndim == 3:
+            c = self._prep(c, "conditions")
+            if c.shape[1] != S:
+                raise ValueError("Condition samples must be equal to number of posterior MC samples.")
+            ct = c.transpose(1, 0)
+            post = self.encoder(torch.cat((x.unsqueeze(0).expand(S, B, x.shape[1]), ct), dim=-1))
+            post = {k: v.view(S, B, -1) for k, v in post.items()}
+            z = self.encoder.rsample(post, num_samples=1).squeeze(0)
+            dec_in = torch.cat((z, ct), dim=-1)
+        else:
+            raise ValueError("Invalid shape for conditions. Must be 2D or 3D tensor.")
+        lik = self.decoder(dec_in.reshape(S * B, -1).contiguous())
+        lik = {k: v.view(S, B, -1) for k, v in lik.items()}
+        return {"params": lik}, {"params": post, "samples": z}
+
     def forward(self, inputs, num_mc_samples=1):
+        if self._graph_mode():
+            return self._forward_graph(inputs, None, num_mc_samples)
         fw = self._run_forward(inputs, None, num_mc_samples)
         return self._pack_outputs(fw)
 
@@ -285,6 +335,12 @@ class VAE(torch.nn.Module):
 
     def loss(self, x, likelihood_params, posterior_params, beta=1.0, prior_params=None):
         """ELBO terms as 0-dim device tensors (reference: src/vae_models.py:70-74)."""
+        if torch.is_grad_enabled() and any(t.requires_grad for d in (likelihood_params, posterior_params) for t in d.values()):
+            if prior_params is not None:
+                prior_params = {k: (v.to(x.device) if torch.is_tensor(v) else v) for k, v in prior_params.items()}
+            rll = self.reconstruction_loglikelihood(x, likelihood_params).mean()
+            kl = self.kl_divergence(posterior_params, prior_params=prior_params).mean()
+            return {"loss": -(rll - beta * kl), "elbo": rll - kl, "rll": rll, "kl": kl}
         rows = self.reconstruction_loglikelihood(x, likelihood_params).reshape(-1).contiguous()
         kl = self.kl_divergence(posterior_params, prior_params=prior_params).reshape(-1).contiguous()
         out = E.elbo_scalars(rows, kl, beta)
@@ -551,6 +607,8 @@ class CVAE(VAE):
     def forward(self, inputs, conditions, num_mc_samples=1):
         if conditions.ndim not in (2, 3):
             raise ValueError("Invalid shape for conditions. Must be 2D or 3D tensor.")
+        if self._graph_mode():
+            return self._forward_graph(inputs, conditions, num_mc_samples)
         fw = self._run_forward(inputs, conditions, num_mc_samples)
         return self._pack_outputs(fw)
 

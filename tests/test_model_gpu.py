@@ -304,3 +304,86 @@ def test_wide_conditioning_3d_fp32_and_bf16(dev):
     m.set_gemm_precision("fp32")
     from behavio_temporal_vae_amd import _native as nv
     nv.set_gemm_precision("fp32")
+
+
+class _FixedRandn:
+    """Make ``torch.randn`` return a given tensor once (the module-level API draws its own noise)."""
+    def __init__(self, eps):
+        self.eps = eps
+
+    def __enter__(self):
+        self._orig = torch.randn
+        def randn(*a, **k):
+            torch.randn = self._orig
+            return self.eps.clone()
+        torch.randn = randn
+
+    def __exit__(self, *exc):
+        torch.randn = self._orig
+
+
+@pytest.mark.parametrize("name", ["tiny_dict_2d", "tiny_normal_2d", "tiny_dict_3d"])
+def test_module_api_autograd_vs_reference(dev, name):
+    """The reference's own training idiom on the module-level API -- forward, loss, ``loss["loss"].backward()`` --
+    builds an autograd graph over the HIP kernels: loss terms and every parameter gradient against the reference."""
+    g = load_golden(name)
+    m = build(g, dev)
+    m.train()
+    m.prior_params = {k: v.to(dev) for k, v in m.prior_params.items()}
+    x, c, eps = T(g["x"]).to(dev), T(g["c"]).to(dev), T(g["train_eps"]).to(dev)
+    S = eps.shape[0]
+    shaped = eps if c.ndim == 2 else eps.unsqueeze(0)
+    with _FixedRandn(shaped):
+        xd, zd = m(x, c, num_mc_samples=S)
+    assert xd["params"]["mu"].requires_grad and zd["params"]["sigma"].requires_grad
+    assert np.allclose(xd["params"]["mu"].detach().cpu().numpy(), g["train_lik_mu"], rtol=1e-4, atol=5e-5)
+    loss = m.loss(x, xd["params"], zd["params"], beta=0.7, prior_params=m.prior_params)
+    for k in ("loss", "elbo", "rll", "kl"):
+        assert abs(loss[k].item() - float(g[f"train_{k}"])) <= 1e-4 * abs(float(g[f"train_{k}"])) + 1e-5, k
+    if name == "tiny_dict_3d":
+        return                                  # the reference fixture holds gradients for the 2-D cases
+    m._grad_arena.zero_()
+    loss["loss"].backward()
+    for k, p in m.named_parameters():
+        ref = g["grad::" + k]
+        scale = np.abs(ref).max() + 1e-8
+        err = np.abs(p.grad.cpu().numpy() - ref).max()
+        assert err <= 5e-4 * scale + 1e-6, (k, err, scale)
+
+
+def test_module_api_with_stock_optimizer(dev):
+    """``torch.optim.Adam`` + ``clip_grad_norm_`` over ``model.parameters()`` with ``zero_grad(set_to_none=True)``:
+    gradient buffers come back as arena views, a second backward accumulates, and the trajectory equals the fused
+    ``train_core`` path step for step."""
+    g = load_golden("tiny_dict_2d")
+    ma, mb = build(g, dev), build(g, dev)
+    for m in (ma, mb):
+        m.train()
+        m.prior_params = {k: v.to(dev) for k, v in m.prior_params.items()}
+        m.train_kwargs = {"num_mc_samples": int(g["S"]), "beta": 0.7, "gradient_clipping": True, "gradient_clipping_kwargs": {"max_norm": 1.0}}
+    opt_a = torch.optim.Adam([{"params": ma.encoder.parameters()}, {"params": ma.decoder.parameters()}], lr=1e-3, weight_decay=1e-5)
+    opt_b = mb.get_optimizer(lr=1e-3, weight_decay=1e-5)
+    for t in range(g["steps_x"].shape[0]):
+        x, c, eps = T(g["steps_x"][t]).to(dev), T(g["steps_c"][t]).to(dev), T(g["steps_eps"][t]).to(dev)
+        with _FixedRandn(eps):
+            xd, zd = ma(x, c, num_mc_samples=eps.shape[0])
+        opt_a.zero_grad(set_to_none=True)
+        la = ma.loss(x, xd["params"], zd["params"], beta=0.7, prior_params=ma.prior_params)
+        la["loss"].backward()
+        assert all(p.grad is not None and p.grad.data_ptr() >= ma._grad_arena.data_ptr() for p in ma.parameters())
+        torch.nn.utils.clip_grad_norm_(ma.parameters(), max_norm=1.0)
+        opt_a.step()
+        lb = mb._train_step(x, c, opt_b, eps=eps)
+        assert rel_err([la[k].item() for k in ("loss", "rll", "kl")], [lb[k].item() for k in ("loss", "rll", "kl")]) < 1e-4
+        assert rel_err([la[k].item() for k in ("loss", "elbo", "rll", "kl")], g["steps_losses"][t]) < 1e-4
+    # accumulation semantics of .backward()
+    x, c, eps = T(g["x"]).to(dev), T(g["c"]).to(dev), T(g["train_eps"]).to(dev)
+    grads = []
+    for reps in (1, 2):
+        ma.zero_grad(set_to_none=True)
+        for _ in range(reps):
+            with _FixedRandn(eps):
+                xd, zd = ma(x, c, num_mc_samples=eps.shape[0])
+            ma.loss(x, xd["params"], zd["params"], beta=0.7, prior_params=ma.prior_params)["loss"].backward()
+        grads.append(ma._grad_arena.clone())
+    assert torch.allclose(grads[1], 2 * grads[0], rtol=2e-3, atol=1e-6)
