@@ -38,6 +38,7 @@ _SIGS = {
     "btvae_bn_fold_eval": [P, P, P, P, F, P, P, I, P],
     "btvae_bn_apply_fwd": [P, P, P, P, P, P, P, F, P, I, I, P],
     "btvae_bn_relu_bwd": [P, P, P, P, P, P, F, P, P, P, P, P, I, I, I, P],
+    "btvae_relu_bwd": [P, P, P, F, P, P, P, I, I, I, P],
     "btvae_dropout_keep_mask": [P, LL, F, ULL, ULL, P],
     "btvae_dirichlet_sample": [P, P, P, I, I, I, I, I, ULL, ULL, P],
     "btvae_colsum": [P, P, P, I, I, I, P],

@@ -76,8 +76,10 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
     float sc[VEC], sh[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        const float s = invstd[col + j] * gamma[col + j];
-        sc[j] = s; sh[j] = beta[col + j] - mean[col + j] * s;
+        if (mean) {
+            const float s = invstd[col + j] * gamma[col + j];
+            sc[j] = s; sh[j] = beta[col + j] - mean[col + j] * s;
+        } else { sc[j] = 1.f; sh[j] = 0.f; }      // no normalisation: dropout / residual only
     }
     const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
 #pragma unroll 4
@@ -194,12 +196,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float invM = 1.f / (float)M;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        mu[j] = ok ? mean[col + j] : 0.f;
-        is[j] = ok ? invstd[col + j] : 0.f;
-        const float gi = ok ? gamma[col + j] * is[j] : 0.f;
+        const bool bn = ok && mean != nullptr;               // null mean: plain ReLU backward (k0 = 1)
+        mu[j] = bn ? mean[col + j] : 0.f;
+        is[j] = bn ? invstd[col + j] : 0.f;
+        const float gi = bn ? gamma[col + j] * is[j] : (ok ? 1.f : 0.f);
         k0[j] = gi;                                          // multiplies g
-        k1[j] = ok ? gi * dbeta[col + j] * invM : 0.f;       // constant term
-        k2[j] = ok ? gi * dgamma[col + j] * invM : 0.f;      // multiplies xhat
+        k1[j] = bn ? gi * dbeta[col + j] * invM : 0.f;       // constant term
+        k2[j] = bn ? gi * dgamma[col + j] * invM : 0.f;      // multiplies xhat
         sb[j] = 0.f;
     }
     const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
@@ -320,7 +323,8 @@ BTVAE_API int btvae_bn_fold_eval(const float* gamma, const float* beta, const fl
 BTVAE_API int btvae_bn_apply_fwd(const float* Y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                  const float* R, const unsigned char* keep, float keep_scale, float* Out, int M, int N,
                                  void* stream) {
-    BTVAE_REQUIRE(Y && mean && invstd && gamma && beta && Out, "bn_apply_fwd: null pointer");
+    BTVAE_REQUIRE(Y && Out, "bn_apply_fwd: null pointer");
+    BTVAE_REQUIRE(mean ? (invstd && gamma && beta) : (!invstd && !gamma && !beta), "bn_apply_fwd: pass all four BatchNorm vectors or none");
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
     ProfScope ps(PK_BN, (hipStream_t)stream, 0, 4.0 * M * N * (R ? 3 : 2) + (keep ? 1.0 * M * N : 0.0));
     if (vec4_ok(N, Y, R, Out, keep))
@@ -365,6 +369,23 @@ BTVAE_API int btvae_dropout_keep_mask(unsigned char* keep, long long n, float p,
     const long long quads = (n + 3) / 4;
     hipLaunchKernelGGL(dropout_keep_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keep, n, p, seed, offset);
     return check_launch("dropout_keep_mask");
+}
+
+// Backward of Linear -> ReLU (-> Dropout) without BatchNorm: dPre = (Y > 0) * dropout(G), dbias (+)= column sums.
+// scratch: btvae_strip_chunks(M) * N floats.
+BTVAE_API int btvae_relu_bwd(const float* G, const float* Y, const unsigned char* keep, float keep_scale, float* dbias,
+                             float* dPre, float* scratch, int M, int N, int accumulate, void* stream) {
+    BTVAE_REQUIRE(G && Y && dbias && dPre && scratch, "relu_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
+    const float* none = nullptr;
+    ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 3 + (keep ? 1.0 * M * N : 0.0));
+    if (vec4_ok(N, G, Y, dPre, keep))
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, scratch, chunks, 1, N, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
+    return check_launch("relu_bwd");
 }
 
 // Scratch floats btvae_bn_relu_bwd needs for an [M,N] activation.

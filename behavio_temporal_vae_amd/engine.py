@@ -127,8 +127,6 @@ DROPOUT = DropoutFeed()
 def _check_train_supported(u: Unit, train: bool):
     if train and u.dropout_p >= 1.0:
         raise ValueError("dropout probability must be below 1")
-    if train and u.act and u.bn is None:
-        raise NotImplementedError("training without batch normalisation is not implemented in the HIP path")
 
 
 def unit_forward(u: Unit, x: torch.Tensor, train: bool, saved: Optional[List[Saved]]) -> torch.Tensor:
@@ -157,6 +155,19 @@ def unit_forward(u: Unit, x: torch.Tensor, train: bool, saved: Optional[List[Sav
                 P(keep), ks, P(out), M, N)
         if saved is not None:
             saved.append(Saved(x, y, mean, invstd, keep, ks))
+    elif u.bn is None and train:
+        # unit built without BatchNorm: y = relu(x W^T + b) is what the backward needs; dropout / residual on top
+        y = torch.empty(M, N, device=dev)
+        nv.call("btvae_linear_relu_affine_fwd", P(x), K, P(W), P(b), None, None, None, P(y), M, K, N)
+        keep, ks = None, 1.0
+        if u.dropout_p > 0.0:
+            keep, ks = DROPOUT.keep(M, N, u.dropout_p, dev), 1.0 / (1.0 - u.dropout_p)
+        if keep is not None or u.residual:
+            nv.call("btvae_bn_apply_fwd", P(y), None, None, None, None, P(x) if u.residual else None, P(keep), ks, P(out), M, N)
+        else:
+            out = y
+        if saved is not None:
+            saved.append(Saved(x, y, None, None, keep, ks))
     else:
         scale = shift = None
         if u.bn is not None:
@@ -223,8 +234,11 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
     dev = g.device
     scr = WS.get("bnbwd", nv.lib().btvae_bn_relu_bwd_scratch(M, N), dev)
     dpre = torch.empty(M, N, device=dev)
-    nv.call("btvae_bn_relu_bwd", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
-            P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)),
+    if u.bn is None:
+        nv.call("btvae_relu_bwd", P(g), P(sv.y), P(sv.keep), float(sv.keep_scale), P(_grad_view(u.lin.bias)), P(dpre), P(scr), M, N, int(accumulate))
+    else:
+        nv.call("btvae_bn_relu_bwd", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
+                P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)),
             P(_grad_view(u.lin.bias)), P(dpre), P(scr), M, N, int(accumulate))
     ws = WS.get("wgrad", WGRAD_WS_FLOATS, dev)
     nv.call("btvae_linear_wgrad", P(dpre), P(sv.x_in), K, P(_grad_view(u.lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))

@@ -76,7 +76,8 @@ int btvae_bn_fold_eval(const float* gamma, const float* beta, const float* runni
 int btvae_dropout_keep_mask(unsigned char* keep, long long n, float p, unsigned long long seed,
                             unsigned long long offset, void* stream);
 /* Out = dropout((Y-mean)*invstd*gamma + beta) (+ R): normalisation, optional dropout (keep NULL = none;
- * kept elements are scaled by keep_scale = 1/(1-p)) and the residual add of src/submodels.py:21,32. */
+ * kept elements are scaled by keep_scale = 1/(1-p)) and the residual add of src/submodels.py:21,32.
+ * mean = invstd = gamma = beta = NULL skips the normalisation (units built without BatchNorm). */
 int btvae_bn_apply_fwd(const float* Y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                        const float* R, const unsigned char* keep, float keep_scale, float* Out, int M, int N,
                        void* stream);
@@ -87,6 +88,10 @@ long long btvae_bn_relu_bwd_scratch(int M, int N);
 int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mean, const float* invstd, const float* gamma,
                       const unsigned char* keep, float keep_scale, float* dgamma, float* dbeta, float* dbias, float* dPre, float* scratch, int M, int N,
                       int accumulate, void* stream);
+/* Backward of Linear -> ReLU (-> Dropout) units built without BatchNorm (batch_normalization: false,
+ * src/submodels.py:15-25): dPre = (Y>0) * dropout(G), dbias (+)= column sums.  scratch: btvae_strip_chunks(M)*N. */
+int btvae_relu_bwd(const float* G, const float* Y, const unsigned char* keep, float keep_scale, float* dbias,
+                   float* dPre, float* scratch, int M, int N, int accumulate, void* stream);
 /* out[N] (+)= column sums of G[M,N]; scratch: btvae_strip_chunks(M)*N floats. */
 int btvae_colsum(const float* G, float* out, float* scratch, int M, int N, int accumulate, void* stream);
 

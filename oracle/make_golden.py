@@ -93,12 +93,15 @@ class DropLog:
         torch.nn.Dropout.forward = self._fwd
 
 
-def case_forward_train(name, lik, seed, D=6, C=4, B=8, S=3, three_d=False, steps=4, dropout=False):
+def case_forward_train(name, lik, seed, D=6, C=4, B=8, S=3, three_d=False, steps=4, dropout=False, bn=True):
     rng = np.random.default_rng(seed)
     cfg = tiny_model_cfg(lik)
     if dropout:
         for d in cfg["distribution_dict"].values():
             d["dropout"] = True
+    if not bn:
+        for d in cfg["distribution_dict"].values():
+            d["batch_normalization"] = False
     torch.manual_seed(seed)
     model = CVAE(input_dim=D, conditioner=Cdim(C), **cfg)
     L = cfg["latent_dim"]
@@ -368,12 +371,16 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dropout":      # only the dropout case (leaves the other fixtures as they are)
         case_forward_train("tiny_dropout_2d", "dict-gauss", seed=6, B=16, dropout=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "nobn":         # only the case without BatchNorm
+        case_forward_train("tiny_nobn_2d", "dict-gauss", seed=8, B=16, dropout=True, bn=False)
+        sys.exit(0)
     case_pointwise()
     case_conditioner()
     case_forward_train("tiny_dict_2d", "dict-gauss", seed=1)
     case_forward_train("tiny_dict_3d", "dict-gauss", seed=2, three_d=True)
     case_forward_train("tiny_normal_2d", "normal", seed=3)
     case_forward_train("tiny_dropout_2d", "dict-gauss", seed=6, B=16, dropout=True)
+    case_forward_train("tiny_nobn_2d", "dict-gauss", seed=8, B=16, dropout=True, bn=False)
     case_scoring()
     case_imputation()
     case_config0_shape()

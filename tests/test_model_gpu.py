@@ -123,11 +123,13 @@ def _keep(g, prefix, dev):
     return out
 
 
-def test_dropout_training_vs_reference(dev):
-    """Train-mode dropout (src/submodels.py:23-25,51) with the reference's recorded keep flags injected: loss
-    terms and every gradient of one step, then four optimiser steps and the final state."""
+@pytest.mark.parametrize("name", ["tiny_dropout_2d", "tiny_nobn_2d"])
+def test_dropout_training_vs_reference(dev, name):
+    """Train-mode dropout (src/submodels.py:23-25,51) with the reference's recorded keep flags injected, for units
+    with and without BatchNorm: loss terms and every gradient of one step, then four optimiser steps and the
+    final state."""
     from behavio_temporal_vae_amd import engine as E
-    g = load_golden("tiny_dropout_2d")
+    g = load_golden(name)
     m = build(g, dev)
     m.train()
     x, c, eps = T(g["x"]).to(dev), T(g["c"]).to(dev), T(g["train_eps"]).to(dev)

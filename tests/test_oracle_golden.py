@@ -95,10 +95,11 @@ def _keep(g, prefix):
     return out
 
 
-def test_dropout_forward_grads_and_steps():
-    """Train-mode dropout with the reference's recorded Bernoulli keep flags: forward terms, every gradient
-    and four optimiser steps."""
-    g = load_golden("tiny_dropout_2d")
+@pytest.mark.parametrize("name", ["tiny_dropout_2d", "tiny_nobn_2d"])
+def test_dropout_forward_grads_and_steps(name):
+    """Train-mode dropout with the reference's recorded Bernoulli keep flags, with and without BatchNorm: forward
+    terms, every gradient and four optimiser steps."""
+    g = load_golden(name)
     spec, _ = golden_spec(g)
     assert spec.enc.dropout and spec.dec.dropout
     sd = golden_state(g)
