@@ -39,6 +39,8 @@ CONFIG0_TRAIN = {"lr": 1e-3, "beta": 1.0, "num_mc_samples": 16, "weight_decay": 
                  "gradient_clipping_kwargs": {"max_norm": 1.0}}
 D, C, SEED = 48, 4, 2112
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X fp32 matrix peak (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD)
+# HBM-side bytes of one launch of the dominant kernel (M=65536, N=K=1000) from PMC passes kept under profiles/
+DOMINANT_KERNEL_HBM_BYTES = 2 * 324658 * 1024 + 304764 * 1024
 
 
 class Cdim:
@@ -259,7 +261,10 @@ def main():
                        "vocab": 100, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": f"gemm_f32_mfma<k-contig,k-contig,relu+stats> M={S * B} N=K=1000 (decoder hidden Linear forward)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "flops_per_launch": dom_fl, "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n, "traffic": None,
+                         "flops_per_launch": dom_fl, "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
+                         "traffic": DOMINANT_KERNEL_HBM_BYTES if (S * B == 65536) else None,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this kernel at this shape, separate passes: profiles/r1_gemm_fwd_pmc.md (not collected live)",
+                         "algorithmic_bytes": 4.0 * (S * B * 1000 + 1000 * 1000 + S * B * 1000),
                          "fwd_family_tflops": fwd_fl / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else None,
                          "all_gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None,
                          "step_model_tflops": flops_per_sample(S) * B / (ms_step * 1e-3) / 1e12},
