@@ -13,6 +13,7 @@ constexpr int STRIP_COLS = 256;   // columns per workgroup: 64 lanes x float4
 // ---- train-mode statistics: merge the per-row-tile (mean, M2) partials of the GEMM epilogue ----
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partials, int ntiles, int tile_rows, int M, int N,
                                                                 float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                                float* __restrict__ m2_out,
                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                 float momentum, float eps) {
     // 32 columns x 8 tile-groups per workgroup: each thread Chan-merges every 8th tile in fp64, the 8 partial
@@ -46,7 +47,8 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
     }
     const double var_b = m2 / n;
     mean_out[c] = (float)mean;
-    invstd_out[c] = (float)(1.0 / sqrt(var_b + (double)eps));
+    if (invstd_out) invstd_out[c] = (float)(1.0 / sqrt(var_b + (double)eps));
+    if (m2_out) m2_out[c] = (float)m2;
     if (running_mean) {
         const double var_u = n > 1.0 ? m2 / (n - 1.0) : var_b;
         running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
@@ -187,13 +189,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ dbeta,
                                                            const unsigned char* __restrict__ keep, float keep_scale,
                                                            float* __restrict__ dPre,
-                                                           float* __restrict__ db_partials, int M, int N, int rows_per_chunk) {
+                                                           float* __restrict__ db_partials, int M, int N, int rows_per_chunk,
+                                                           float invM) {          // 1 / rows the statistics were taken over
     __shared__ float red[4][64][VEC];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + lane) * VEC;
     const bool ok = col < N;
     float mu[VEC], is[VEC], k0[VEC], k1[VEC], k2[VEC], sb[VEC];
-    const float invM = 1.f / (float)M;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const bool bn = ok && mean != nullptr;               // null mean: plain ReLU backward (k0 = 1)
@@ -309,8 +311,32 @@ BTVAE_API int btvae_bn_stats_finalize(const float* partials, int ntiles, int M, 
     BTVAE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize: pass both running buffers or neither");
     ProfScope ps(PK_BN, (hipStream_t)stream, 0, 8.0 * ntiles * N);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, ntiles, 128, M, N,
-                       mean, invstd, running_mean, running_var, momentum, eps);
+                       mean, invstd, (float*)nullptr, running_mean, running_var, momentum, eps);
     return check_launch("bn_stats_finalize");
+}
+
+// Statistics of this rank's rows only, in mergeable form: local[0][c] = column mean, local[1][c] = M2 (sum of squared
+// deviations) from the GEMM's per-tile partials.
+BTVAE_API int btvae_bn_stats_local(const float* partials, int ntiles, int M, int N, float* local, void* stream) {
+    BTVAE_REQUIRE(partials && local, "bn_stats_local: null pointer");
+    BTVAE_REQUIRE(ntiles == (M + 127) / 128, "bn_stats_local: ntiles %d does not match M %d", ntiles, M);
+    ProfScope ps(PK_BN, (hipStream_t)stream, 0, 8.0 * ntiles * N);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, ntiles, 128, M, N,
+                       local, (float*)nullptr, local + N, (float*)nullptr, (float*)nullptr, 0.f, 0.f);
+    return check_launch("bn_stats_local");
+}
+
+// Merge the (mean, M2) pairs of `parts` ranks that each hold `rows_per_part` rows (parts[p][0|1][N], the layout an
+// all-gather of btvae_bn_stats_local outputs has) into the statistics of the whole batch; running buffers as in
+// btvae_bn_stats_finalize.
+BTVAE_API int btvae_bn_stats_merge(const float* parts, int nparts, int rows_per_part, int N, float* mean, float* invstd,
+                                   float* running_mean, float* running_var, float momentum, float eps, void* stream) {
+    BTVAE_REQUIRE(parts && mean && invstd && nparts > 0 && rows_per_part > 0, "bn_stats_merge: bad argument");
+    BTVAE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_merge: pass both running buffers or neither");
+    ProfScope ps(PK_BN, (hipStream_t)stream, 0, 8.0 * nparts * N);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, parts, nparts, rows_per_part,
+                       nparts * rows_per_part, N, mean, invstd, (float*)nullptr, running_mean, running_var, momentum, eps);
+    return check_launch("bn_stats_merge");
 }
 
 BTVAE_API int btvae_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
@@ -354,8 +380,8 @@ BTVAE_API int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mea
     float* cur_dbeta = scratch + (size_t)3 * chunks * N;
     float* cur_dgamma = cur_dbeta + N;
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, p2, chunks, 2, N, dbeta, dgamma, cur_dbeta, cur_dgamma, accumulate);
-    if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc);
-    else    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc);
+    if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc, 1.f / (float)M);
+    else    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc, 1.f / (float)M);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, p1, chunks, 1, N, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
     return check_launch("bn_relu_bwd");
 }
@@ -371,6 +397,40 @@ BTVAE_API int btvae_dropout_keep_mask(unsigned char* keep, long long n, float p,
     return check_launch("dropout_keep_mask");
 }
 
+// The two halves of btvae_bn_relu_bwd for statistics that span several ranks.  First half: this rank's column sums
+// sums[0][c] = sum g, sums[1][c] = sum g*xhat (xhat from the GLOBAL mean / invstd), also added into dbeta / dgamma.
+// The caller sum-all-reduces `sums` over the ranks and passes the result with the global row count to the second half.
+BTVAE_API int btvae_bn_relu_bwd_sums(const float* G, const float* Y, const float* mean, const float* invstd,
+                                     const unsigned char* keep, float keep_scale, float* dgamma, float* dbeta, float* sums,
+                                     float* scratch, int M, int N, int accumulate, void* stream) {
+    BTVAE_REQUIRE(G && Y && mean && invstd && dgamma && dbeta && sums && scratch, "bn_relu_bwd_sums: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
+    ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 2 + (keep ? 1.0 * M * N : 0.0));
+    if (vec4_ok(N, G, Y, nullptr, keep)) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, scratch, M, N, rpc);
+    else                                 hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, scratch, M, N, rpc);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, scratch, chunks, 2, N, dbeta, dgamma, sums, sums + N, accumulate);
+    return check_launch("bn_relu_bwd_sums");
+}
+
+// Second half: dPre and dbias from the batch-wide sums (sums[0] = sum g, sums[1] = sum g*xhat over total_rows rows).
+BTVAE_API int btvae_bn_relu_bwd_apply(const float* G, const float* Y, const float* mean, const float* invstd, const float* gamma,
+                                      const unsigned char* keep, float keep_scale, const float* sums, long long total_rows,
+                                      float* dbias, float* dPre, float* scratch, int M, int N, int accumulate, void* stream) {
+    BTVAE_REQUIRE(G && Y && mean && invstd && gamma && sums && dbias && dPre && scratch, "bn_relu_bwd_apply: null pointer");
+    BTVAE_REQUIRE(total_rows >= M, "bn_relu_bwd_apply: total_rows %lld < local rows %d", total_rows, M);
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
+    const float inv = 1.f / (float)total_rows;
+    ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 3 + (keep ? 1.0 * M * N : 0.0));
+    if (vec4_ok(N, G, Y, dPre, keep))
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, rpc, inv);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, rpc, inv);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, scratch, chunks, 1, N, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
+    return check_launch("bn_relu_bwd_apply");
+}
+
 // Backward of Linear -> ReLU (-> Dropout) without BatchNorm: dPre = (Y > 0) * dropout(G), dbias (+)= column sums.
 // scratch: btvae_strip_chunks(M) * N floats.
 BTVAE_API int btvae_relu_bwd(const float* G, const float* Y, const unsigned char* keep, float keep_scale, float* dbias,
@@ -381,9 +441,9 @@ BTVAE_API int btvae_relu_bwd(const float* G, const float* Y, const unsigned char
     const float* none = nullptr;
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 3 + (keep ? 1.0 * M * N : 0.0));
     if (vec4_ok(N, G, Y, dPre, keep))
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc, 1.f);
     else
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc, 1.f);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, scratch, chunks, 1, N, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
     return check_launch("relu_bwd");
 }

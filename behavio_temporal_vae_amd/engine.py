@@ -41,6 +41,7 @@ class Saved:
     invstd: Optional[torch.Tensor] = None
     keep: Optional[torch.Tensor] = None      # uint8 dropout keep flags of the unit's output
     keep_scale: float = 1.0
+    total_rows: int = 0                      # rows the BatchNorm statistics span (> local rows under cross-rank sync)
 
 
 class NetPlan:
@@ -122,6 +123,7 @@ class DropoutFeed:
 
 
 DROPOUT = DropoutFeed()
+BN_SYNC = None      # parallel.BatchNormSync while BatchNorm statistics span the ranks of a process group, else None
 
 
 def _check_train_supported(u: Unit, train: bool):
@@ -146,15 +148,24 @@ def unit_forward(u: Unit, x: torch.Tensor, train: bool, saved: Optional[List[Sav
         mean, invstd = torch.empty(N, device=dev), torch.empty(N, device=dev)
         track = u.bn.track_running_stats and u.bn.running_mean is not None
         mom = u.bn.momentum if u.bn.momentum is not None else 0.1
-        nv.call("btvae_bn_stats_finalize", P(part), tiles, M, N, P(mean), P(invstd),
-                P(u.bn.running_mean) if track else None, P(u.bn.running_var) if track else None, float(mom), float(u.bn.eps))
+        total_rows = M
+        if BN_SYNC is not None and BN_SYNC.world > 1:
+            local = torch.empty(2, N, device=dev)
+            nv.call("btvae_bn_stats_local", P(part), tiles, M, N, P(local))
+            parts = BN_SYNC.gather_stats(local)
+            total_rows = M * BN_SYNC.world
+            nv.call("btvae_bn_stats_merge", P(parts), BN_SYNC.world, M, N, P(mean), P(invstd),
+                    P(u.bn.running_mean) if track else None, P(u.bn.running_var) if track else None, float(mom), float(u.bn.eps))
+        else:
+            nv.call("btvae_bn_stats_finalize", P(part), tiles, M, N, P(mean), P(invstd),
+                    P(u.bn.running_mean) if track else None, P(u.bn.running_var) if track else None, float(mom), float(u.bn.eps))
         keep, ks = None, 1.0
         if u.dropout_p > 0.0:
             keep, ks = DROPOUT.keep(M, N, u.dropout_p, dev), 1.0 / (1.0 - u.dropout_p)
         nv.call("btvae_bn_apply_fwd", P(y), P(mean), P(invstd), P(u.bn.weight), P(u.bn.bias), P(x) if u.residual else None,
                 P(keep), ks, P(out), M, N)
         if saved is not None:
-            saved.append(Saved(x, y, mean, invstd, keep, ks))
+            saved.append(Saved(x, y, mean, invstd, keep, ks, total_rows))
     elif u.bn is None and train:
         # unit built without BatchNorm: y = relu(x W^T + b) is what the backward needs; dropout / residual on top
         y = torch.empty(M, N, device=dev)
@@ -236,10 +247,18 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
     dpre = torch.empty(M, N, device=dev)
     if u.bn is None:
         nv.call("btvae_relu_bwd", P(g), P(sv.y), P(sv.keep), float(sv.keep_scale), P(_grad_view(u.lin.bias)), P(dpre), P(scr), M, N, int(accumulate))
+    elif sv.total_rows > M:
+        # statistics span ranks: local column sums -> sum over ranks -> dPre with the batch-wide sums
+        sums = torch.empty(2, N, device=dev)
+        nv.call("btvae_bn_relu_bwd_sums", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(sv.keep), float(sv.keep_scale),
+                P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)), P(sums), P(scr), M, N, int(accumulate))
+        BN_SYNC.sum_(sums)
+        nv.call("btvae_bn_relu_bwd_apply", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
+                P(sums), int(sv.total_rows), P(_grad_view(u.lin.bias)), P(dpre), P(scr), M, N, int(accumulate))
     else:
         nv.call("btvae_bn_relu_bwd", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
                 P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)),
-            P(_grad_view(u.lin.bias)), P(dpre), P(scr), M, N, int(accumulate))
+                P(_grad_view(u.lin.bias)), P(dpre), P(scr), M, N, int(accumulate))
     ws = WS.get("wgrad", WGRAD_WS_FLOATS, dev)
     nv.call("btvae_linear_wgrad", P(dpre), P(sv.x_in), K, P(_grad_view(u.lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
     if not need_dx:

@@ -16,6 +16,48 @@ import torch.distributed as dist
 from .loaders import shard_range  # noqa: F401  (re-exported)
 
 
+def _staged(group) -> bool:
+    """gloo moves host memory: device tensors are staged through the host (tests on one GPU); RCCL takes them as is."""
+    return dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    if t.is_cuda and _staged(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def all_gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
+    """[world, *local.shape] with every rank's ``local`` (contiguous)."""
+    world = dist.get_world_size(group)
+    if local.is_cuda and _staged(group):
+        parts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(world)]
+        dist.all_gather(parts, local.cpu(), group=group)
+        return torch.stack(parts).to(local.device)
+    out = torch.empty((world, *local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out.view(world * local.shape[0], *local.shape[1:]), local.contiguous(), group=group)
+    return out
+
+
+class BatchNormSync:
+    """Cross-rank BatchNorm statistics (``torch.nn.SyncBatchNorm`` semantics): with it, N ranks on 1/N of the batch
+    each compute what one device computes on the whole batch.  Every rank must hold the same number of rows."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def gather_stats(self, local: torch.Tensor) -> torch.Tensor:      # [2, N] -> [world, 2, N]
+        return all_gather_rows(local, self.group)
+
+    def sum_(self, sums: torch.Tensor) -> torch.Tensor:               # [2, N] in place
+        return all_reduce_sum_(sums, self.group)
+
+
 class GradSync:
     """Asynchronous sum all-reduce of arena spans; ``finish`` waits for all of them.  The caller divides by
     ``world`` afterwards (on the GPU with the library's scale kernel)."""
@@ -27,7 +69,10 @@ class GradSync:
 
     def launch(self, span: torch.Tensor):
         if self.world > 1:
-            self._handles.append(dist.all_reduce(span, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if span.is_cuda and _staged(self.group):
+                all_reduce_sum_(span, self.group)
+            else:
+                self._handles.append(dist.all_reduce(span, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         for h in self._handles:
@@ -36,7 +81,7 @@ class GradSync:
 
     def sum_(self, t: torch.Tensor) -> torch.Tensor:
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            all_reduce_sum_(t, self.group)
         return t
 
 

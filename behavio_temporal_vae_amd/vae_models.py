@@ -386,12 +386,16 @@ class VAE(torch.nn.Module):
         return out
 
     # ------------------------------------------------------------------ data parallel hooks
-    def enable_data_parallel(self, process_group=None):
+    def enable_data_parallel(self, process_group=None, sync_batchnorm=False):
         """Average gradients (and the reported loss terms) over the ranks of ``process_group`` (RCCL) in
-        every ``train_core``.  Decoder gradients are reduced while the encoder backward still runs."""
-        from .parallel import GradSync
+        every ``train_core``.  Decoder gradients are reduced while the encoder backward still runs.
+        ``sync_batchnorm=True`` also makes the BatchNorm statistics span the ranks (equal rows per rank), so N ranks
+        on 1/N of a batch each reproduce the single-device step on the whole batch; the default keeps them per
+        rank, as ``DistributedDataParallel`` over the reference's modules would."""
+        from .parallel import BatchNormSync, GradSync
         self._dp_sync = GradSync(process_group)
         self._dp_world = self._dp_sync.world
+        E.BN_SYNC = BatchNormSync(process_group) if (sync_batchnorm and self._dp_world > 1) else None
 
     def _grads_ready(self, which: str):
         if self._dp_world <= 1:

@@ -68,6 +68,12 @@ int btvae_strip_chunks(int M);
  * NULL) move with `momentum` using the unbiased variance. */
 int btvae_bn_stats_finalize(const float* partials, int ntiles, int M, int N, float* mean, float* invstd,
                             float* running_mean, float* running_var, float momentum, float eps, void* stream);
+/* Statistics that span ranks (torch.nn.SyncBatchNorm semantics for the BatchNorm1d of src/submodels.py:20-21,50):
+ * btvae_bn_stats_local leaves this rank's local[0] = mean, local[1] = M2; after an all-gather,
+ * btvae_bn_stats_merge combines `nparts` such pairs of `rows_per_part` rows each. */
+int btvae_bn_stats_local(const float* partials, int ntiles, int M, int N, float* local, void* stream);
+int btvae_bn_stats_merge(const float* parts, int nparts, int rows_per_part, int N, float* mean, float* invstd,
+                         float* running_mean, float* running_var, float momentum, float eps, void* stream);
 /* Eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale. */
 int btvae_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, float* scale, float* shift, int N, void* stream);
@@ -88,6 +94,15 @@ long long btvae_bn_relu_bwd_scratch(int M, int N);
 int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mean, const float* invstd, const float* gamma,
                       const unsigned char* keep, float keep_scale, float* dgamma, float* dbeta, float* dbias, float* dPre, float* scratch, int M, int N,
                       int accumulate, void* stream);
+/* btvae_bn_relu_bwd in two halves with a sum-all-reduce of sums[2][N] between them (statistics spanning ranks):
+ * _sums leaves this rank's (sum g, sum g*xhat) and adds them into dbeta / dgamma; _apply takes the batch-wide sums
+ * and the global row count.  scratch as for btvae_bn_relu_bwd. */
+int btvae_bn_relu_bwd_sums(const float* G, const float* Y, const float* mean, const float* invstd,
+                           const unsigned char* keep, float keep_scale, float* dgamma, float* dbeta, float* sums,
+                           float* scratch, int M, int N, int accumulate, void* stream);
+int btvae_bn_relu_bwd_apply(const float* G, const float* Y, const float* mean, const float* invstd, const float* gamma,
+                            const unsigned char* keep, float keep_scale, const float* sums, long long total_rows,
+                            float* dbias, float* dPre, float* scratch, int M, int N, int accumulate, void* stream);
 /* Backward of Linear -> ReLU (-> Dropout) units built without BatchNorm (batch_normalization: false,
  * src/submodels.py:15-25): dPre = (Y>0) * dropout(G), dbias (+)= column sums.  scratch: btvae_strip_chunks(M)*N. */
 int btvae_relu_bwd(const float* G, const float* Y, const unsigned char* keep, float keep_scale, float* dbias,

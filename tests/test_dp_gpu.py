@@ -1,0 +1,103 @@
+"""GPU: data-parallel training with BatchNorm statistics spanning the ranks.  Two processes share the one GPU of the
+test box and talk over gloo (device tensors staged through the host by ``parallel.py``; on a multi-GPU node the same
+code runs over RCCL).  With synchronised BatchNorm, two ranks on half a batch each must reproduce the single-device
+step on the whole batch: loss terms per step and the parameters after four optimiser steps."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import golden_state, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+class Cdim:
+    def __init__(self, c):
+        self.cond_dim = c
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(g, dev):
+    from behavio_temporal_vae_amd.vae_models import CVAE
+    cfg = json.loads(str(g["model_cfg"]))
+    m = CVAE(input_dim=int(g["D"]), conditioner=Cdim(int(g["C"])), **cfg)
+    m.load_state_dict(golden_state(g))
+    m = m.to(dev).train()
+    m.train_kwargs = {"num_mc_samples": int(g["S"]), "beta": 0.7, "gradient_clipping": True, "gradient_clipping_kwargs": {"max_norm": 1.0}}
+    return m
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = torch.device("cuda:0")
+        T = lambda a: torch.from_numpy(np.array(a)).to(dev)
+        g = load_golden("tiny_dict_2d")
+        steps = g["steps_x"].shape[0]
+        B = g["steps_x"].shape[1]
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        out = {}
+        for mode in ("single", "sync", "per_rank"):
+            m = _build(g, dev)
+            if mode != "single":
+                m.enable_data_parallel(sync_batchnorm=(mode == "sync"))
+            opt = m.get_optimizer(lr=1e-3, weight_decay=1e-5)
+            losses = []
+            for t in range(steps):
+                x, c, eps = T(g["steps_x"][t]), T(g["steps_c"][t]), T(g["steps_eps"][t])
+                if mode != "single":
+                    x, c, eps = x[lo:hi].contiguous(), c[lo:hi].contiguous(), eps[:, lo:hi].contiguous()
+                l = m._train_step(x, c, opt, eps=eps)
+                losses.append([l[k].item() for k in ("loss", "elbo", "rll", "kl")])
+            sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if v.is_floating_point()}
+            out[mode] = (np.array(losses), sd)
+            from behavio_temporal_vae_amd import engine as E
+            E.BN_SYNC = None
+        q.put((rank, out, None))
+        dist.destroy_process_group()
+    except Exception as exc:     # surface the failure in the parent instead of a silent non-zero exit
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+        raise exc
+
+
+def test_syncbn_two_ranks_equal_single_device():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=170) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, out, err in res:
+        assert err is None, err
+    g = load_golden("tiny_dict_2d")
+    for rank, out, _ in res:
+        single_l, single_sd = out["single"]
+        sync_l, sync_sd = out["sync"]
+        per_l, _ = out["per_rank"]
+        # the single-device run is itself pinned to the reference
+        assert np.max(np.abs(single_l - g["steps_losses"]) / (np.abs(g["steps_losses"]) + 1e-6)) < 1e-4
+        assert np.max(np.abs(sync_l - single_l) / (np.abs(single_l) + 1e-6)) < 1e-4, (rank, sync_l, single_l)
+        for k, v in single_sd.items():
+            assert np.abs(sync_sd[k] - v).max() <= 5e-4 * (np.abs(v).max() + 1e-6), k
+        # per-rank statistics (the default) are a different computation: the check above is not vacuous
+        assert np.max(np.abs(per_l - single_l) / (np.abs(single_l) + 1e-6)) > 1e-3
+    assert np.array_equal(res[0][1]["sync"][0], res[1][1]["sync"][0])        # both ranks report the same averaged terms
