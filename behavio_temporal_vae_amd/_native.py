@@ -44,6 +44,7 @@ _SIGS = {
     "btvae_bn_relu_bwd_sums": [P, P, P, P, P, F, P, P, P, P, I, I, I, P],
     "btvae_bn_relu_bwd_apply": [P, P, P, P, P, P, F, P, LL, P, P, P, I, I, I, P],
     "btvae_dropout_keep_mask": [P, LL, F, ULL, ULL, P],
+    "btvae_sample_error_update": [P, P, P, P, I, I, I, I, P],
     "btvae_dirichlet_sample": [P, P, P, I, I, I, I, I, ULL, ULL, P],
     "btvae_colsum": [P, P, P, I, I, I, P],
     "btvae_reparam_kl_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, ULL, ULL, P],

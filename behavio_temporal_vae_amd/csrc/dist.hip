@@ -298,6 +298,24 @@ __global__ __launch_bounds__(256) void iw_lse_update_kernel(const float* __restr
     if (lane == 0) { m_run[n] = m; s_run[n] = s; }
 }
 
+// Sample errors of posterior-predictive draws, streamed like the logsumexp: e1[n] (+)= sum_k sum_d |xs - x|,
+// e2[n] (+)= sum_k sum_d (xs - x)^2 over the kc draws of a chunk.  One wave per profile n.
+__global__ __launch_bounds__(256) void sample_error_update_kernel(const float* __restrict__ xs, const float* __restrict__ x,
+                                                                  float* __restrict__ e1, float* __restrict__ e2,
+                                                                  int kc, int N, int D, int first) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < kc; ++k)
+        for (int d = lane; d < D; d += 64) {
+            const float df = xs[((size_t)k * N + n) * D + d] - x[(size_t)n * D + d];
+            a += fabsf(df); b += df * df;
+        }
+    a = wave_sum(a); b = wave_sum(b);
+    if (lane == 0) { e1[n] = first ? a : e1[n] + a; e2[n] = first ? b : e2[n] + b; }
+}
+
 __global__ void iw_lse_finalize_kernel(const float* __restrict__ m_run, const float* __restrict__ s_run, float* __restrict__ ll, int N, float logK) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n < N) ll[n] = m_run[n] + logf(s_run[n]) - logK;
@@ -415,4 +433,13 @@ BTVAE_API int btvae_iw_lse_finalize(const float* m_run, const float* s_run, floa
     BTVAE_REQUIRE(m_run && s_run && ll && N > 0 && K > 0, "iw_lse_finalize: bad arguments");
     hipLaunchKernelGGL(iw_lse_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, m_run, s_run, ll, N, logf((float)K));
     return check_launch("iw_lse_finalize");
+}
+
+BTVAE_API int btvae_sample_error_update(const float* xs, const float* x, float* e1, float* e2, int kc, int N, int D, int first,
+                                        void* stream) {
+    BTVAE_REQUIRE(xs && x && e1 && e2, "sample_error_update: null pointer");
+    BTVAE_REQUIRE(kc > 0 && N > 0 && D > 0, "sample_error_update: empty problem kc=%d N=%d D=%d", kc, N, D);
+    ProfScope ps(PK_REDUCE, (hipStream_t)stream, 0, 4.0 * ((double)kc * N * D + (double)N * D));
+    hipLaunchKernelGGL(sample_error_update_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, xs, x, e1, e2, kc, N, D, first);
+    return check_launch("sample_error_update");
 }

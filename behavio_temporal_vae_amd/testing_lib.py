@@ -72,6 +72,68 @@ def iw_loglikelihood_device(model, x, c, num_mc_samples, mc_sample_batch_size=10
 
 
 @torch.no_grad()
+def test_metrics_device(model, x, c, num_mc_samples, mc_sample_batch_size=40, eps=None, eps_x=None):
+    """What ``scripts/collect_testing_results.py:84-113`` derives from ``mass_reconstruction``'s host buffers, streamed on
+    the device: importance-weighted log-likelihood, KL, and the l1 / l2 errors of one posterior-predictive sample per
+    latent draw -- err_p[n] = (mean_k sum_d |x_s[k,n,d] - x[n,d]|^p)^(1/p).  ``eps[K,N,L]`` (latent noise) and
+    ``eps_x[K,N,V or D]`` (sample noise) may be injected."""
+    model._check_arena()
+    N, L, K, D = x.shape[0], model.latent_dim, num_mc_samples, model.input_dim
+    x, c = nv.f32(x), nv.f32(c)
+    dev = x.device
+    dec = model.decoder
+    is_dict = isinstance(dec, DictionaryGaussian)
+    post = _encode(model, x, c)
+    m_run, s_run = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    e1, e2 = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    Uh = dec.get_SigmaMapper() if is_dict else None
+    for i0, i1 in _chunks(K, mc_sample_batch_size):
+        kc = i1 - i0
+        e = eps[i0:i1].contiguous() if eps is not None else torch.randn((kc, N, L), device=dev)
+        _, lik, logp = _decode_chunk(model, post, c, e, x, N)
+        nv.call("btvae_iw_lse_update", nv.ptr(logp), nv.ptr(e.reshape(-1, L)), nv.ptr(post["mu"]), nv.ptr(post["sigma"]),
+                nv.ptr(m_run), nv.ptr(s_run), kc, N, L, int(i0 == 0))
+        W = lik["sigma"].shape[1]
+        ex = eps_x[i0:i1].reshape(-1, W).contiguous() if eps_x is not None else torch.randn((kc * N, W), device=dev)
+        xs = torch.empty(kc * N, D, device=dev)
+        if is_dict:          # mu + Uhat (eps * sigma)   (src/submodels.py:160-164)
+            scaled = (ex * lik["sigma"]).contiguous()
+            nv.call("btvae_matmul_nt_add", nv.ptr(scaled), W, nv.ptr(Uh), W, nv.ptr(lik["mu"]), D, nv.ptr(xs), D, kc * N, D, W)
+        else:
+            torch.addcmul(lik["mu"], lik["sigma"], ex, out=xs)
+        nv.call("btvae_sample_error_update", nv.ptr(xs), nv.ptr(x), nv.ptr(e1), nv.ptr(e2), kc, N, D, int(i0 == 0))
+    ll = torch.empty(N, device=dev)
+    nv.call("btvae_iw_lse_finalize", nv.ptr(m_run), nv.ptr(s_run), nv.ptr(ll), N, K)
+    _, kl, _ = E.reparam_kl(post["mu"], post["sigma"], torch.zeros(N, L, device=dev), None, 1, False, N)
+    return {"loglikelihood": ll, "kl": kl, "l_1": e1 / K, "l_2": torch.sqrt(e2 / K)}
+
+
+@torch.no_grad()
+def mass_test_metrics(model, x, conditioner, condition_set, num_mc_samples=100, batch_size=50000, mc_sample_batch_size=40, device="cpu"):
+    """Per-profile test metrics of a whole set as numpy arrays {"loglikelihood", "kl", "l_1", "l_2"} without the
+    ``[K,N,.]`` host buffers (27 GB at K=100 on the reference's test split) that the reference's collection script
+    goes through.  Deterministic conditioners only (the sampled-condition case keeps the buffer route)."""
+    if conditioner.is_random() if hasattr(conditioner, "is_random") else False:
+        raise NotImplementedError("streamed test metrics need deterministic conditions; use mass_reconstruction for sampled ones")
+    N = x.shape[0]
+    model.to(device)
+    model._prior_to(device)
+    out = {k: np.empty(N, np.float32) for k in ("loglikelihood", "kl", "l_1", "l_2")}
+    feed = ConditionFeed(x, condition_set, conditioner, batch_size, device=device)
+    for k, (b0, b1, xb, cb) in enumerate(feed):
+        print(f"Batch {k+1}/{len(feed)}")
+        res = test_metrics_device(model, xb, cb, num_mc_samples, min(mc_sample_batch_size, num_mc_samples))
+        for key, v in res.items():
+            out[key][b0:b1] = v.cpu().numpy()
+    model.to("cpu")
+    model._prior_to("cpu")
+    return out
+
+
+test_metrics_device.__test__ = False      # not a pytest test despite the name
+
+
+@torch.no_grad()
 def mass_loglikelihood(model, x, conditioner, condition_set, num_mc_samples=1, batch_size=10000, mc_sample_batch_size=100, device="cpu"):
     """(loglikelihood[N], rlls[K,N], kl[N]) as numpy arrays (reference: src/testing_lib.py:6-16)."""
     if conditioner.is_random() if hasattr(conditioner, "is_random") else False:

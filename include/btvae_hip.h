@@ -162,6 +162,11 @@ int btvae_masked_scatter(float* dst, const long long* idx, const float* src, lon
 int btvae_lse_over_k(const float* logp, float* out, int K, int B, void* stream);
 int btvae_pack_lower(const float* full, float* packed, long long rows, int D, void* stream);
 
+/* Streaming accumulation of the l1 / l2 sample errors of scripts/collect_testing_results.py:104-113 over chunks of
+ * draws xs[kc,N,D] against x[N,D]: e1[n] (+)= sum |xs-x|, e2[n] (+)= sum (xs-x)^2 (first != 0 overwrites). */
+int btvae_sample_error_update(const float* xs, const float* x, float* e1, float* e2, int kc, int N, int D, int first,
+                              void* stream);
+
 /* ---- condition feed ---- */
 /* Dirichlet draws of DirichletTransformer.transform(style "sample") (src/utils.py:112-129: gamma(alpha,1) draws
  * normalised per row) made on the device and written into the [B, S, ldo] condition tensor at column col0:

@@ -286,6 +286,45 @@ def case_scoring(name="scoring_tiny", seed=5, N=20, K=7, D=6):
     print("wrote", name)
 
 
+def case_test_metrics(name="test_metrics_tiny", seed=12, N=18, K=6, D=6):
+    """The per-profile metrics of scripts/collect_testing_results.py:84-113 on a tiny model, with every draw logged."""
+    rng = np.random.default_rng(seed)
+    cfg = tiny_model_cfg("dict-gauss")
+    cond, cset = make_conditioner(N, rng)
+    torch.manual_seed(seed)
+    model = CVAE(input_dim=D, conditioner=cond, **cfg)
+    model.train()
+    with torch.no_grad():
+        for _ in range(3):
+            model.forward(torch.tensor(synth_profiles(16, D, rng)), torch.tensor(rng.normal(size=(16, 4)).astype(np.float32)), num_mc_samples=2)
+    model.eval()
+    X = synth_profiles(N, D, rng)
+    with DrawLog() as log:
+        x_rec, z_rec, rlls = testing_lib.mass_reconstruction(model, X, cond, cset, num_mc_samples=K, batch_size=7, mc_sample_batch_size=4, device="cpu")
+    L = cfg["latent_dim"]
+    eps = np.zeros((K, N, L), np.float32)
+    it = iter(log.randn[1:])                      # first call is the shape probe (src/testing_lib.py:27)
+    for k0 in range(0, N, 7):
+        for i0 in range(0, K, 4):
+            d = next(it).numpy()
+            eps[i0:i0 + d.shape[0], k0:k0 + d.shape[1]] = d
+    with torch.no_grad():
+        post_ll = model.encoder.log_likelihood(z_rec["samples"], z_rec["params"])
+        prior_ll = model.encoder.log_likelihood(z_rec["samples"], model.prior_params)
+        kl = model.kl_divergence(z_rec["params"], prior_params=model.prior_params)
+    ll = (-torch.log(torch.tensor(rlls.shape[0])) + torch.logsumexp(-post_ll + rlls + prior_ll, dim=0)).numpy()
+    with DrawLog() as log2:
+        x_samples = model.decoder.sample(x_rec["params"])[0].cpu().detach().numpy()
+    eps_x = log2.randn[0].numpy()[0]              # [K, N, V]
+    errors = {f"l_{p}": np.mean((np.abs(x_samples - X[None, ...]) ** p).sum(axis=-1), axis=0) ** (1 / p) for p in (1, 2)}
+    out = {"model_cfg": json.dumps(cfg), "D": D, "N": N, "K": K, "x": X, "c": cond.transform(cset).astype(np.float32),
+           "months": cset["months"], "weekdays": cset["weekdays"], "eps": eps, "eps_x": eps_x,
+           "loglikelihood": ll, "kl": kl.numpy(), "l_1": errors["l_1"], "l_2": errors["l_2"]}
+    out.update(np_state(model.state_dict()))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name)
+
+
 def case_imputation(name="imputation_tiny", seed=9, N=10, D=6, W=3, T=5, num_samples=3):
     rng = np.random.default_rng(seed)
     cfg = tiny_model_cfg("dict-gauss")
@@ -371,6 +410,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dropout":      # only the dropout case (leaves the other fixtures as they are)
         case_forward_train("tiny_dropout_2d", "dict-gauss", seed=6, B=16, dropout=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":      # only the test-metrics case
+        case_test_metrics()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "nobn":         # only the case without BatchNorm
         case_forward_train("tiny_nobn_2d", "dict-gauss", seed=8, B=16, dropout=True, bn=False)
         sys.exit(0)
@@ -382,5 +424,6 @@ if __name__ == "__main__":
     case_forward_train("tiny_dropout_2d", "dict-gauss", seed=6, B=16, dropout=True)
     case_forward_train("tiny_nobn_2d", "dict-gauss", seed=8, B=16, dropout=True, bn=False)
     case_scoring()
+    case_test_metrics()
     case_imputation()
     case_config0_shape()

@@ -437,6 +437,27 @@ def iw_loglikelihood(sd: Dict[str, Tensor], spec: ModelSpec, x: Tensor, c: Tenso
     return ll, rlls, kl
 
 
+def test_metrics(sd: Dict[str, Tensor], spec: ModelSpec, x: Tensor, c: Tensor, eps: Tensor, eps_x: Tensor) -> Dict[str, Tensor]:
+    """Per-profile test metrics of scripts/collect_testing_results.py:84-113: importance-weighted log-likelihood, KL, and
+    the l_p errors (p = 1, 2) of one posterior-predictive sample per latent draw,
+    err_p[n] = (mean_k sum_d |x_s[k,n,d] − x[n,d]|^p)^(1/p) with x_s = mu + Û(eps_x ⊙ sigma) (src/submodels.py:160-164)."""
+    K, N = eps.shape[0], x.shape[0]
+    ll, _, kl = iw_loglikelihood(sd, spec, x, c, eps)
+    post = dist_forward(sd, "encoder", spec.enc, torch.cat((x, c), -1), False)
+    z = post["mu"] + post["sigma"] * eps
+    lik = dist_forward(sd, "decoder", spec.dec, torch.cat((z, c.unsqueeze(0).expand(K, N, c.shape[-1])), -1), False)
+    lik = {k: v.view(K, N, -1) for k, v in lik.items()}
+    if spec.dec.kind == "dict":
+        xs = dict_rsample(sd["decoder.SigmaMapper"], lik["mu"], lik["sigma"], eps_x)
+    else:
+        xs = lik["mu"] + lik["sigma"] * eps_x
+    diff = (xs - x.unsqueeze(0)).abs()
+    return {"loglikelihood": ll, "kl": kl, "l_1": diff.sum(-1).mean(0), "l_2": (diff ** 2).sum(-1).mean(0).sqrt()}
+
+
+test_metrics.__test__ = False
+
+
 def prior_sample_loglik(sd: Dict[str, Tensor], spec: ModelSpec, x: Tensor, c: Tensor, z: Tensor) -> Tensor:
     """Prior-sample scoring: decoder on z~N(0,I) ‖ c, log p(x|z,c) per sample
     (src/vae_models.py:283-290 followed by ``decoder.log_likelihood``). ``z[K,B,L]`` → ``[K,B]``."""

@@ -142,6 +142,14 @@ def test_scoring():
     assert rel_err(pr.numpy(), g["prior_rll"]) < 1e-4
 
 
+def test_streamed_test_metrics():
+    g = load_golden("test_metrics_tiny")
+    spec, _ = golden_spec(g)
+    res = R.test_metrics(golden_state(g), spec, T(g["x"]), T(g["c"]), T(g["eps"]), T(g["eps_x"]))
+    for k in ("loglikelihood", "kl", "l_1", "l_2"):
+        assert rel_err(res[k].numpy(), g[k]) < 1e-4, k
+
+
 def test_imputation():
     g = load_golden("imputation_tiny")
     spec, _ = golden_spec(g)

@@ -276,3 +276,31 @@ def test_device_condition_feed_dirichlet(dev):
     ds = ConditionedDataset(rng.normal(size=(n, 6)).astype(np.float32), cset, cond, num_samples=3)
     x, cb = next(iter(DeviceBatchLoader(ds, 16, shuffle=True, drop_last=True, device=dev)))
     assert x.shape == (16, 6) and cb.shape == (16, 3, cond.cond_dim) and cb.is_cuda
+
+
+def test_streamed_test_metrics_vs_reference(dev, tmp_path):
+    """Per-profile IW log-likelihood, KL and l1/l2 sample errors as the reference's collection script derives them
+    from its host buffers (scripts/collect_testing_results.py:84-113), here streamed on the device with the same
+    draws injected; then the two result files with the reference's columns / keys."""
+    import pickle
+    import pandas as pd
+    from behavio_temporal_vae_amd import results_lib, testing_lib
+    g = load_golden("test_metrics_tiny")
+    cond, _ = make_cond(g)
+    m = build(g, dev, cond)
+    x, c = T(g["x"]).to(dev), T(g["c"]).to(dev)
+    res = testing_lib.test_metrics_device(m, x, c, int(g["K"]), mc_sample_batch_size=4, eps=T(g["eps"]).to(dev), eps_x=T(g["eps_x"]).to(dev))
+    for k in ("loglikelihood", "kl", "l_1", "l_2"):
+        assert rel_err(res[k].cpu().numpy(), g[k]) < 1e-4, k
+    metrics = {k: v.cpu().numpy() for k, v in res.items()}
+    users, months = np.arange(int(g["N"])) // 3, g["months"][:, 0]
+    frame = results_lib.test_results_frame(metrics, users, months, "test")
+    agg = results_lib.test_results_aggregate(metrics)
+    results_lib.save_test_results(str(tmp_path), {"test": frame}, {"test": agg})
+    back = pd.read_csv(tmp_path / "test_results_raw.csv")
+    assert list(back.columns) == ["l_1", "l_2", "loglikelihood", "user_id", "month", "set_type"]
+    assert np.allclose(back["loglikelihood"].values, g["loglikelihood"], rtol=1e-4) and set(back["set_type"]) == {"test"}
+    with open(tmp_path / "test_results_aggregate.pkl", "rb") as f:
+        a = pickle.load(f)
+    assert set(a["test"]) == {"loglikelihood", "error_l_1", "error_l_2"}
+    assert abs(a["test"]["error_l_2"] - float(g["l_2"].mean())) <= 1e-4 * abs(float(g["l_2"].mean()))
