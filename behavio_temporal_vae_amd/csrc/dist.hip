@@ -161,11 +161,16 @@ __global__ __launch_bounds__(64) void dict_grad_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// MVN rows.  One wave per row; lane i holds row i of the D x D covariance in registers (DP >= D,
-// padded with identity).  BWD: in-place Gauss-Jordan inversion (pivots = LDL^T pivots, so
-// logdet = sum log pivot), alpha = Sigma^-1 (x - mu), P = alpha alpha^T - Sigma^-1.
-// Outputs: logp; dmu_raw = g*alpha*dfac_mu; Pg packed = g * P * (1 on the diagonal, 2 off it).
-// !BWD: forward elimination only (half the work): maha = sum y_k^2 / d_k.
+// MVN rows.  One wave per row; lane i holds row i of the D x D covariance in registers (DP >= D, a multiple of 4,
+// padded with identity).  The matrix stays symmetric through the elimination, so the pivot row a step needs is the
+// pivot COLUMN, one value per lane: each lane drops its value into a per-wave LDS line and the whole row comes back
+// as broadcast 16-byte reads (lane reads cost several times more than these on this chip).  The pivot loop is a
+// real loop over groups of 4 pivots with the register row rotated by 4 per group, so the 4 pivot columns of a group
+// are always registers 0..3 and LDS reads stay 16-byte aligned (the line is stored twice back to back, which turns
+// the rotation's wrap-around into a plain offset).
+// BWD: symmetric sweep (A <- -Sigma^-1, pivots = LDL^T pivots so logdet = sum log pivot), alpha = Sigma^-1 (x - mu),
+// P = alpha alpha^T - Sigma^-1.  Outputs: logp; dmu_raw = g*alpha*dfac_mu; Pg packed = g * P * (1 on the diagonal,
+// 2 off it).  !BWD: forward elimination only (half the work): maha = sum y_k^2 / d_k.
 // ---------------------------------------------------------------------------------------------
 template <int DP, bool BWD>
 __global__ __launch_bounds__(256) void mvn_rows_kernel(const float* __restrict__ Sp, const float* __restrict__ mu,
@@ -173,14 +178,17 @@ __global__ __launch_bounds__(256) void mvn_rows_kernel(const float* __restrict__
                                                        const float* __restrict__ g_rows, float g_const,
                                                        float* __restrict__ logp, float* __restrict__ dmu_raw,
                                                        float* __restrict__ Pg, int rows, int B, int D) {
+    static_assert(DP % 4 == 0 && DP <= 64, "padded dimension must be a multiple of 4, at most 64");
     constexpr int NPMAX = DP * (DP + 1) / 2;
     __shared__ float sh[4][NPMAX];
+    __shared__ __attribute__((aligned(16))) float line[4][2 * DP + 4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int row_raw = blockIdx.x * 4 + w;
     const bool live = row_raw < rows;
     const int row = live ? row_raw : rows - 1;
     const int NP = D * (D + 1) / 2;
     const int i = lane;
+    float* cw = line[w];
 
     for (int p = lane; p < NP; p += 64) sh[w][p] = Sp[(size_t)row * NP + p];
     __syncthreads();
@@ -196,40 +204,57 @@ __global__ __launch_bounds__(256) void mvn_rows_kernel(const float* __restrict__
     float r = 0.f;
     if (i < D) r = x[(size_t)(row % B) * D + i] - mu[(size_t)row * D + i];
 
-    // The pivot loop is a real loop (small code, stays in the instruction cache): instead of indexing the
-    // register row by k, the row is rotated left by one column per step, so the pivot column is always
-    // register 0 and after DP steps the columns are back in place.
-    float logdet = 0.f, maha = 0.f, alpha = 0.f;
-    if (BWD) {
-#pragma unroll 1
-        for (int k = 0; k < DP; ++k) {
-            const float piv = readlane_f(a[0], k);
-            logdet += logf(piv);
-            const float rp = 1.f / piv;
-            const float gk = (i == k) ? (1.f - rp) : a[0] * rp;
-            const float last = (i == k) ? rp : -gk;
+    // Every lane of this wave publishes v; afterwards s[j] = value of lane (k + j) mod DP.  The line is written
+    // twice back to back (wrap-around becomes an offset) and shifted by m = -k mod 4 floats so that the reads,
+    // which start at lane k's slot, are 16-byte aligned for every k.
+    auto exchange = [&](float v, int k, float (&s)[DP]) {
+        const int m = (4 - (k & 3)) & 3;
+        if (i < DP) { cw[i + m] = v; cw[i + m + DP] = v; }
+        __builtin_amdgcn_wave_barrier();
+        const float* src = cw + (k + m);
 #pragma unroll
-            for (int j = 1; j < DP; ++j) { const float s = readlane_f(a[j], k); a[j - 1] = fmaf(-gk, s, a[j]); }
-            a[DP - 1] = last;
+        for (int j = 0; j < DP; j += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(src + j);
+            s[j] = t.x; s[j + 1] = t.y; s[j + 2] = t.z; s[j + 3] = t.w;
         }
-#pragma unroll
-        for (int j = 0; j < DP; ++j) alpha = fmaf(a[j], readlane_f(r, j), alpha);
-        maha = wave_sum(r * alpha);
-    } else {
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // The register row is rotated left by one column per step (each FMA writes the slot to its left), so the pivot
+    // column is always register 0 and after DP steps the columns are back in place.
+    float logdet = 0.f, maha = 0.f, alpha = 0.f;
 #pragma unroll 1
-        for (int k = 0; k < DP; ++k) {
-            const float piv = readlane_f(a[0], k);
-            logdet += logf(piv);
-            const float rp = 1.f / piv;
+    for (int k = 0; k < DP; ++k) {
+        const float c = a[0];
+        float s[DP];
+        exchange(c, k, s);                            // s[j] = A[k][column held by register j]; s[0] is the pivot
+        const float piv = s[0];
+        logdet += logf(piv);
+        const float rp = 1.f / piv;
+        if (BWD) {
+            const float gk = (i == k) ? (1.f - rp) : c * rp;
+#pragma unroll
+            for (int j = 1; j < DP; ++j) a[j - 1] = fmaf(-gk, s[j], a[j]);
+            a[DP - 1] = (i == k) ? -rp : gk;
+        } else {
             const float yk = readlane_f(r, k);
             maha = fmaf(yk * yk, rp, maha);
-            const float f = (i > k) ? a[0] * rp : 0.f;
+            const float f = (i > k) ? c * rp : 0.f;
             r = fmaf(-f, yk, r);
-            const float keep = a[0];
 #pragma unroll
-            for (int j = 1; j < DP; ++j) { const float s = readlane_f(a[j], k); a[j - 1] = fmaf(-f, s, a[j]); }
-            a[DP - 1] = keep;
+            for (int j = 1; j < DP; ++j) a[j - 1] = fmaf(-f, s[j], a[j]);
+            a[DP - 1] = c;
         }
+    }
+    float av[DP];                                      // BWD: alpha of every lane, for P
+    if (BWD) {
+        // a = -Sigma^-1 with its columns back in place: alpha_i = -sum_j a[j] r_j
+        float rv[DP];
+        exchange(r, 0, rv);
+#pragma unroll
+        for (int j = 0; j < DP; ++j) alpha = fmaf(-a[j], rv[j], alpha);
+        maha = wave_sum(r * alpha);
+        exchange(alpha, 0, av);
     }
     const float lp = -0.5f * ((float)D * LOG_2PI + maha) - 0.5f * logdet;
     if (live && lane == 0) logp[row] = lp;
@@ -239,10 +264,8 @@ __global__ __launch_bounds__(256) void mvn_rows_kernel(const float* __restrict__
         if (live && i < D) dmu_raw[(size_t)row * D + i] = g * alpha * dfac_mu[(size_t)row * D + i];
         __syncthreads();   // every wave has finished gathering from sh
 #pragma unroll
-        for (int j = 0; j < DP; ++j) {
-            const float aj = readlane_f(alpha, j);
-            if (i < D && j <= i) sh[w][i * (i + 1) / 2 + j] = g * (alpha * aj - a[j]) * (i == j ? 1.f : 2.f);
-        }
+        for (int j = 0; j < DP; ++j)
+            if (i < D && j <= i) sh[w][i * (i + 1) / 2 + j] = g * (alpha * av[j] + a[j]) * (i == j ? 1.f : 2.f);
         __syncthreads();
         if (live) for (int p = lane; p < NP; p += 64) Pg[(size_t)row * NP + p] = sh[w][p];
     }

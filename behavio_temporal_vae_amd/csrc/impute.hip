@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void cond_mvn_kernel(const float* __restrict__
 
     // sweep on observed pivots.  Real loop with the register row rotated left by one column per step
     // (pivot column always in register 0; after DP steps the columns are back in place).
+    float prow[DP];
 #pragma unroll 1
     for (int k = 0; k < DP; ++k) {
         const bool piv_obs = k < D && ((obs_mask >> k) & 1ull);
@@ -58,7 +59,9 @@ __global__ __launch_bounds__(256) void cond_mvn_kernel(const float* __restrict__
             last = (i == k) ? rp : -gk;
         }
 #pragma unroll
-        for (int j = 1; j < DP; ++j) { const float s = readlane_f(a[j], k); a[j - 1] = fmaf(-gk, s, a[j]); }
+        for (int j = 1; j < DP; ++j) prow[j] = readlane_f(a[j], k);     // pivot row to scalars first, then the FMAs
+#pragma unroll
+        for (int j = 1; j < DP; ++j) a[j - 1] = fmaf(-gk, prow[j], a[j]);
         a[DP - 1] = last;
     }
     // conditional mean of unobserved lane i: mu_i - sum_{k in O} A[i][k] r_k
@@ -91,7 +94,9 @@ __global__ __launch_bounds__(256) void cond_mvn_kernel(const float* __restrict__
             sm = fmaf((i == k) ? 1.f : fe, ek, sm);
         }
 #pragma unroll
-        for (int j = 1; j < DP; ++j) { const float s = readlane_f(a[j], k); a[j - 1] = fmaf(-fe, s, a[j]); }
+        for (int j = 1; j < DP; ++j) prow[j] = readlane_f(a[j], k);
+#pragma unroll
+        for (int j = 1; j < DP; ++j) a[j - 1] = fmaf(-fe, prow[j], a[j]);
         a[DP - 1] = keep;
     }
     if (live && is_un) samp[(size_t)row * U + myu] = sm;
