@@ -2,8 +2,8 @@
 // on the observed coordinates, draw the missing ones, and the equal-weight mixture log-likelihood of
 // held-out targets.  One wave per profile; lane i holds row i of the covariance in registers.
 //
-// Sweeping the covariance on the observed pivots (Gauss-Jordan steps restricted to k in O) leaves
-//   A[u][o] = -Sigma_uo Sigma_oo^-1     and     A[u][u'] = Sigma_uu - Sigma_uo Sigma_oo^-1 Sigma_ou
+// Sweeping the covariance on the observed pivots (symmetric sweep steps restricted to k in O) leaves
+//   A[u][o] = Sigma_uo Sigma_oo^-1     and     A[u][u'] = Sigma_uu - Sigma_uo Sigma_oo^-1 Sigma_ou
 // i.e. the regression coefficients and the conditional covariance in place.  A forward LDL^T
 // elimination over the unobserved pivots then yields the Cholesky factor columns one at a time,
 // which is all a draw mean + L eps needs.
@@ -23,8 +23,10 @@ __global__ __launch_bounds__(256) void cond_mvn_kernel(const float* __restrict__
                                                        unsigned long long obs_mask, const int* __restrict__ un_pos,
                                                        float* __restrict__ samp, float* __restrict__ cmean, float* __restrict__ ccov,
                                                        int rows, int D, int U) {
+    static_assert(DP % 4 == 0 && DP <= 64, "padded dimension must be a multiple of 4, at most 64");
     constexpr int NPMAX = DP * (DP + 1) / 2;
     __shared__ float sh[4][NPMAX];
+    __shared__ __attribute__((aligned(16))) float line[4][2 * DP + 4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int row_raw = blockIdx.x * 4 + w;
     const bool live = row_raw < rows;
@@ -38,6 +40,7 @@ __global__ __launch_bounds__(256) void cond_mvn_kernel(const float* __restrict__
     for (int j = 0; j < DP; ++j) {
         float v = (i == j) ? 1.f : 0.f;
         if (i < D && j < D) { const int mx = max(i, j), mn = min(i, j); v = sh[w][mx * (mx + 1) / 2 + mn]; }
+        if (i >= DP) v = 0.f;
         a[j] = v;
     }
     const bool is_obs = i < D && ((obs_mask >> i) & 1ull);
@@ -45,32 +48,50 @@ __global__ __launch_bounds__(256) void cond_mvn_kernel(const float* __restrict__
     const float mui = i < D ? mu[(size_t)row * D + i] : 0.f;
     const float ri = is_obs ? x[(size_t)row * D + i] - mui : 0.f;    // residual of observed coordinates
 
-    // sweep on observed pivots.  Real loop with the register row rotated left by one column per step
+    // Every lane publishes v in a per-wave LDS line; afterwards s[j] = value of lane (k + j) mod DP, fetched with
+    // broadcast 16-byte reads (the line is stored twice back to back and shifted so the reads are aligned for any k).
+    // The matrix stays symmetric under the sweep, so the pivot ROW a step needs is the pivot COLUMN across lanes.
+    float* cw = line[w];
+    auto exchange = [&](float v, int k, float (&s)[DP]) {
+        const int m = (4 - (k & 3)) & 3;
+        if (i < DP) { cw[i + m] = v; cw[i + m + DP] = v; }
+        __builtin_amdgcn_wave_barrier();
+        const float* src = cw + (k + m);
+#pragma unroll
+        for (int j = 0; j < DP; j += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(src + j);
+            s[j] = t.x; s[j + 1] = t.y; s[j + 2] = t.z; s[j + 3] = t.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // symmetric sweep on the observed pivots.  Real loop with the register row rotated left by one column per step
     // (pivot column always in register 0; after DP steps the columns are back in place).
-    float prow[DP];
+    float s[DP];
 #pragma unroll 1
     for (int k = 0; k < DP; ++k) {
-        const bool piv_obs = k < D && ((obs_mask >> k) & 1ull);
-        float gk = 0.f, last = a[0];
+        const bool piv_obs = k < D && ((obs_mask >> k) & 1ull);      // wave-uniform
+        const float c = a[0];
         if (piv_obs) {
-            const float piv = readlane_f(a[0], k);
-            const float rp = 1.f / piv;
-            gk = (i == k) ? (1.f - rp) : a[0] * rp;
-            last = (i == k) ? rp : -gk;
+            exchange(c, k, s);
+            const float rp = 1.f / s[0];
+            const float gk = (i == k) ? (1.f - rp) : c * rp;
+#pragma unroll
+            for (int j = 1; j < DP; ++j) a[j - 1] = fmaf(-gk, s[j], a[j]);
+            a[DP - 1] = (i == k) ? -rp : gk;
+        } else {
+#pragma unroll
+            for (int j = 1; j < DP; ++j) a[j - 1] = a[j];
+            a[DP - 1] = c;
         }
-#pragma unroll
-        for (int j = 1; j < DP; ++j) prow[j] = readlane_f(a[j], k);     // pivot row to scalars first, then the FMAs
-#pragma unroll
-        for (int j = 1; j < DP; ++j) a[j - 1] = fmaf(-gk, prow[j], a[j]);
-        a[DP - 1] = last;
     }
-    // conditional mean of unobserved lane i: mu_i - sum_{k in O} A[i][k] r_k
+    // now A[u][o] = (Sigma_uo Sigma_oo^-1)[u][o] and A[u][u'] = conditional covariance:
+    // conditional mean of unobserved lane i = mu_i + sum_{k in O} A[i][k] r_k
     float cm = mui;
+    exchange(ri, 0, s);
 #pragma unroll
-    for (int k = 0; k < DP; ++k) {
-        const float rk = readlane_f(ri, k);
-        if (k < D && ((obs_mask >> k) & 1ull)) cm = fmaf(-a[k], rk, cm);
-    }
+    for (int k = 0; k < DP; ++k)
+        if (k < D && ((obs_mask >> k) & 1ull)) cm = fmaf(a[k], s[k], cm);
     const int myu = is_un ? un_pos[i] : 0;           // position of coordinate i among the unobserved ones
     if (live && is_un) {
         cmean[(size_t)row * U + myu] = cm;
@@ -83,21 +104,22 @@ __global__ __launch_bounds__(256) void cond_mvn_kernel(const float* __restrict__
     float sm = cm;
 #pragma unroll 1
     for (int k = 0; k < DP; ++k) {
-        const bool piv_un = k < D && !((obs_mask >> k) & 1ull);
-        float fe = 0.f;
-        const float keep = a[0];
+        const bool piv_un = k < D && !((obs_mask >> k) & 1ull);       // wave-uniform
+        const float c = a[0];
         if (piv_un) {
-            const float piv = readlane_f(a[0], k);
+            exchange(c, k, s);
+            const float piv = s[0];
             const float rp = 1.f / piv;
             const float ek = readlane_f(ei, k) * sqrtf(piv);
-            fe = (is_un && i > k) ? a[0] * rp : 0.f;
+            const float fe = (is_un && i > k) ? c * rp : 0.f;
             sm = fmaf((i == k) ? 1.f : fe, ek, sm);
+#pragma unroll
+            for (int j = 1; j < DP; ++j) a[j - 1] = fmaf(-fe, s[j], a[j]);
+        } else {
+#pragma unroll
+            for (int j = 1; j < DP; ++j) a[j - 1] = a[j];
         }
-#pragma unroll
-        for (int j = 1; j < DP; ++j) prow[j] = readlane_f(a[j], k);
-#pragma unroll
-        for (int j = 1; j < DP; ++j) a[j - 1] = fmaf(-fe, prow[j], a[j]);
-        a[DP - 1] = keep;
+        a[DP - 1] = c;
     }
     if (live && is_un) samp[(size_t)row * U + myu] = sm;
 }
