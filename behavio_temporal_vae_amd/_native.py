@@ -138,7 +138,7 @@ def f32(t, name="tensor"):
     return t.contiguous()
 
 
-GEMM_PRECISIONS = {"fp32": 0, "bf16": 1}
+GEMM_PRECISIONS = {"fp32": 0, "bf16": 1, "fp32_split": 2}
 
 
 def set_gemm_precision(name: str):

@@ -39,8 +39,18 @@ CONFIG0_TRAIN = {"lr": 1e-3, "beta": 1.0, "num_mc_samples": 16, "weight_decay": 
                  "gradient_clipping_kwargs": {"max_norm": 1.0}}
 D, C, SEED = 48, 4, 2112
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X fp32 matrix peak (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD)
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X bf16 dense matrix peak (v_mfma_f32_32x32x16_bf16, 1024 FLOP/clk/SIMD)
+SPLIT_TERMS = 6                  # bf16 MFMAs issued per fp32 product in the split mode
 # HBM-side bytes of one launch of the dominant kernel (M=65536, N=K=1000) from PMC passes kept under profiles/
 DOMINANT_KERNEL_HBM_BYTES = 2 * 324658 * 1024 + 304764 * 1024
+
+
+PRECISION_NOTE = {
+    "fp32_split": "Linear products: fp32 operands as exact 3-way bf16 splits, 6 bf16 MFMAs per product with fp32 accumulation; "
+                  "error against fp64 at or below the fp32 MFMA instruction's (tools/gemm_accuracy.py)",
+    "fp32": "Linear products on the fp32 MFMA instruction",
+    "bf16": "Linear products on bf16-rounded operands",
+}
 
 
 class Cdim:
@@ -132,7 +142,8 @@ def scoring_benchmark(dev, rank, world, n_profiles, K, chunk):
     flops = (5_076_000 + K * 5_152_000) * 2.0 * cnt
     return {"metric": "MC-scored profiles/sec at K=1000", "value": cnt / dt, "unit": "profiles/s", "K": K, "profiles": cnt,
             "seconds": dt, "mean_loglik": tot / cnt, "model_tflops": flops / dt / 1e12,
-            "config": {"workload": "config0_gipuzkoa-shaped IW log-likelihood, eval mode", "input_dim": 24, "latent_dim": 24,
+            "config": {"workload": "config0_gipuzkoa-shaped IW log-likelihood, eval mode", "gemm_precision": model.gemm_precision,
+                       "input_dim": 24, "latent_dim": 24,
                        "hidden": 1000, "vocab": 100, "mc_chunk": chunk, "per_gpu_profiles": n_profiles}}
 
 
@@ -143,7 +154,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bf16-steps", type=int, default=10, help="extra train steps with bf16 GEMM operands, reported under 'bf16_option' (0 = skip)")
+    ap.add_argument("--option-steps", "--bf16-steps", dest="option_steps", type=int, default=10,
+                    help="extra train steps per alternative GEMM precision (native fp32 MFMA, bf16 operands), reported beside the headline (0 = skip)")
     ap.add_argument("--scoring-profiles", type=int, default=4096, help="per-GPU profiles of the K=1000 scoring leg (0 = skip)")
     ap.add_argument("--scoring-k", type=int, default=1000)
     ap.add_argument("--scoring-chunk", type=int, default=25, help="latent draws per decoder pass")
@@ -208,17 +220,16 @@ def main():
     if not all(math.isfinite(v) for v in last.values()):
         raise SystemExit(f"non-finite loss terms: {last}")
 
-    bf16_opt = None
-    if args.bf16_steps > 0:
-        # optional mode, never the headline value: same step with the Linear products on bf16 operands
-        model.set_gemm_precision("bf16")
+    def timed_option(precision, steps, what):
+        """Same step with another operand precision for the Linear products; never the headline value."""
+        model.set_gemm_precision(precision)
         for i in range(3):
             step(i)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         tb = time.perf_counter()
-        for i in range(args.bf16_steps):
+        for i in range(steps):
             lb = step(i)
         if world > 1:
             dist.barrier()
@@ -228,11 +239,15 @@ def main():
             t = torch.tensor([tb], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tb = float(t.item())
-        bf16_opt = {"metric": "ELBO train samples/sec (bf16 GEMM operands, fp32 accumulate and fp32 everywhere else)",
-                    "value": world * B * args.bf16_steps / tb, "unit": "samples/s", "ms_per_step": tb / args.bf16_steps * 1e3,
-                    "steps": args.bf16_steps, "last_loss": float(lb["loss"].item())}
-        model.set_gemm_precision("fp32")
-        nv.set_gemm_precision("fp32")
+        model.set_gemm_precision(main_precision)
+        return {"metric": f"ELBO train samples/sec ({what})", "value": world * B * steps / tb, "unit": "samples/s",
+                "ms_per_step": tb / steps * 1e3, "steps": steps, "last_loss": float(lb["loss"].item())}
+
+    main_precision = model.gemm_precision
+    native_opt = bf16_opt = None
+    if args.option_steps > 0:
+        native_opt = timed_option("fp32", args.option_steps, "Linear products on the fp32 MFMA instruction, v_mfma_f32_32x32x2_f32")
+        bf16_opt = timed_option("bf16", args.option_steps, "bf16 GEMM operands, fp32 accumulate and fp32 everywhere else")
 
     scoring = None
     if args.scoring_profiles > 0:
@@ -249,6 +264,12 @@ def main():
         fwd_ms, fwd_fl, _, fwd_n = prof["gemm_fwd"]
         # dominant kernel: the Linear+ReLU+column-statistics GEMM at the decoder's hidden shape (S*B x H x H)
         achieved = dom_fl * dom_n / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        if main_precision == "fp32_split":
+            peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS
+            peak_note = "fp32-equivalent FLOP/s: bf16 dense peak 2500 / 6 bf16 MFMAs per fp32 product"
+        else:
+            peak = PEAK_F32_MFMA_TFLOPS if main_precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            peak_note = "dense matrix peak of the operand type"
         kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[3] / args.steps,
                        "tflops": (v[1] / (v[0] * 1e-3) / 1e12 if v[0] > 0 and v[1] > 0 else None),
                        "gbps": (v[2] / (v[0] * 1e-3) / 1e9 if v[0] > 0 and v[2] > 0 else None)} for k, v in prof.items()}
@@ -256,13 +277,15 @@ def main():
             "metric": "ELBO train samples/sec", "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "config0.json training step, fused ELBO fwd/bwd + clip + Adam, fp32 MFMA", "global_batch": world * B,
+            "config": {"workload": "config0.json training step, fused ELBO fwd/bwd + clip + Adam, fp32 (" + PRECISION_NOTE[main_precision] + ")",
+                       "gemm_precision": main_precision, "global_batch": world * B,
                        "per_gpu_batch": B, "num_mc_samples": S, "input_dim": D, "cond_dim": C, "latent_dim": 48, "hidden": 1000,
                        "vocab": 100, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_f32_mfma<k-contig,k-contig,relu+stats> M={S * B} N=K=1000 (decoder hidden Linear forward)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": f"gemm_f32_mfma<k-contig,k-contig,relu+stats,{main_precision}> M={S * B} N=K=1000 (decoder hidden Linear forward)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": peak_note,
+                         "fp32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                          "flops_per_launch": dom_fl, "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
-                         "traffic": DOMINANT_KERNEL_HBM_BYTES if (S * B == 65536) else None,
+                         "traffic": DOMINANT_KERNEL_HBM_BYTES if (S * B == 65536) else None,   # same loads/stores in both fp32 modes
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this kernel at this shape, separate passes: profiles/r1_gemm_fwd_pmc.md (not collected live)",
                          "algorithmic_bytes": 4.0 * (S * B * 1000 + 1000 * 1000 + S * B * 1000),
                          "fwd_family_tflops": fwd_fl / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else None,
@@ -273,6 +296,8 @@ def main():
         }
         if scoring is not None:
             out["secondary"] = scoring
+        if native_opt is not None:
+            out["fp32_mfma_option"] = native_opt
         if bf16_opt is not None:
             out["bf16_option"] = bf16_opt
         if world == 1 and not args.no_cpu_baseline:

@@ -20,6 +20,8 @@ def main():
     nv.ensure_device(dev)
     if os.environ.get("BTVAE_BENCH_BF16"):
         nv.set_gemm_precision("bf16")
+    if os.environ.get("BTVAE_BENCH_PREC"):
+        nv.set_gemm_precision(os.environ["BTVAE_BENCH_PREC"])
     M = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
     N = K = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
     g = torch.Generator(device=dev).manual_seed(0)
