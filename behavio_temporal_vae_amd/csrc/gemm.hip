@@ -13,6 +13,7 @@
 // vector rate (64 FLOP/clk/SIMD), so the kernel is MFMA-issue bound; LDS and L2 have >4x slack.
 #include "gemm_common.h"
 #include "gemm_bf16.h"
+#include "gemm_split.h"
 #include <algorithm>
 #include <atomic>
 
@@ -363,12 +364,12 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     const int prec = g_precision.load(std::memory_order_relaxed);
     const bool bf16 = reduced_ok && prec == 1 && a.a_vec && a.b_vec;
     const bool split = reduced_ok && prec == 2 && a.a_vec && a.b_vec;
-    const int bk = bf16 ? HBK : BK;
+    const int bk = bf16 ? HBK : split ? SBK : BK;
     a.kchunk = (((a.K + splits - 1) / splits) + bk - 1) / bk * bk;
     splits = (a.K + a.kchunk - 1) / a.kchunk;
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)splits);
     if (bf16)                    hipLaunchKernelGGL((gemm_bf16_mfma<AL, BL, EPI>), grid, dim3(256), 0, s, a);
-    else if (split)              hipLaunchKernelGGL((gemm_f32_mfma<AL, BL, EPI, true, true>), grid, dim3(256), 0, s, a);
+    else if (split)              hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI>), grid, dim3(256), 0, s, a);
     else if (a.a_vec && a.b_vec) hipLaunchKernelGGL((gemm_f32_mfma<AL, BL, EPI, true>), grid, dim3(256), 0, s, a);
     else                    hipLaunchKernelGGL((gemm_f32_mfma<AL, BL, EPI, false>), grid, dim3(256), 0, s, a);
     return btvae::check_launch(what);

@@ -1,0 +1,250 @@
+// fp32 products on the bf16 matrix pipe, operands split once while staging.
+//
+// An fp32 value is the exact sum of three bf16 values h + m + l (8 significant bits each, taken by truncation), so
+// a*b = nine bf16 x bf16 products, each exact in fp32.  The six largest (hh, hm, mh, mm, hl, lh) are issued as
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped three are below 2^-21 of |a*b|.  Six bf16 MFMAs of
+// 16 k cost 192 matrix-pipe cycles where the eight fp32 MFMAs of 2 k they replace cost 512.
+//
+// 128x128x16 block tile, 4 waves (2x2) of 64x64, register staging several k-tiles deep (global latency is longer than
+// one tile's 24 MFMAs), double-buffered LDS, one barrier per k-tile.
+// Operands stay fp32 in HBM; each thread splits the 16 values it stages per tile into the three bf16 planes of its
+// operand and stores them k-contiguously: an LDS plane is [128 rows][16 k] bf16 with 32-byte rows, swizzled instead
+// of padded (s_off), one 16-byte read per plane and MFMA operand: 48 KiB per workgroup.
+// m/n-contiguous operands are transposed in registers (2k x 4m patch per thread).
+#pragma once
+#include "gemm_common.h"
+
+namespace btvae_gemm {
+
+constexpr int SBK = 16;                  // k elements per tile = one bf16 MFMA step
+constexpr int SPLANE = 128 * SBK;        // bf16 elements per plane (4 KiB)
+
+typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
+
+// Element offset of (row, 8-k half c) inside a plane.  Rows are permuted inside groups of four (low two bits XORed
+// with the next two) and the two 16-byte halves swap on every second group of eight: with that, the 16-byte fragment
+// reads, the 8-byte stores of k-contiguous operands and the 4-byte stores of transposed operands are all free of
+// bank conflicts (checked by enumeration against the per-instruction lane groups and bank widths).
+__device__ __forceinline__ int s_off(int row, int c) {
+    const int pr = (row & ~3) | ((row ^ (row >> 2)) & 3);
+    return pr * SBK + ((c ^ ((pr >> 3) & 1)) << 3);
+}
+
+// (x0, x1) -> packed bf16 pairs of their high / middle / low pieces (x0 in the low half)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& H, unsigned& M, unsigned& L) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
+    const unsigned s0 = __float_as_uint(r0), s1 = __float_as_uint(r1);
+    const float l0 = r0 - __uint_as_float(s0 & 0xFFFF0000u), l1 = r1 - __uint_as_float(s1 & 0xFFFF0000u);
+    H = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    M = __builtin_amdgcn_perm(s1, s0, 0x07060302u);
+    L = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+}
+
+struct SStage { float v[8]; };           // 8 staged fp32 values per thread and operand
+
+__device__ __forceinline__ void sput4(SStage& st, int slot, const float4 a) {
+    st.v[4 * slot] = a.x; st.v[4 * slot + 1] = a.y; st.v[4 * slot + 2] = a.z; st.v[4 * slot + 3] = a.w;
+}
+
+// LAY_K: thread f (two passes) owns row f>>2, k = 4*(f&3) .. +3.  LAY_M: thread owns k = 2*(tid&7), +1 and
+// m = 4*(tid>>3) .. +3.
+template <int LAY, bool FULL>
+__device__ __forceinline__ void s_g2r(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int kend,
+                                      int tid, SStage& st) {
+    if (LAY == LAY_K) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = tid + 256 * q;
+            const int gr = row0 + (f >> 2), gk = k0 + ((f & 3) << 2);
+            const float* src = P + (size_t)min(gr, nrows - 1) * ld + gk;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FULL) a = *reinterpret_cast<const float4*>(src);
+            else if (gr < nrows && gk + 3 < kend) a = *reinterpret_cast<const float4*>(src);
+            sput4(st, q, a);
+        }
+    } else {
+        const int kp = tid & 7, mq = tid >> 3;
+        const int gm = row0 + (mq << 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gk = k0 + kp * 2 + j;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FULL) a = *reinterpret_cast<const float4*>(P + (size_t)gk * ld + min(gm, nrows - 4));
+            else if (gk < kend && gm + 3 < nrows) a = *reinterpret_cast<const float4*>(P + (size_t)gk * ld + gm);
+            sput4(st, j, a);         // v[4j + i] = element (k = 2kp + j, m = 4mq + i)
+        }
+    }
+}
+
+// split the staged values and store the three planes of one operand (planes at S, S + SPLANE, S + 2*SPLANE)
+template <int LAY>
+__device__ __forceinline__ void s_r2s(__bf16* S, int tid, const SStage& st) {
+    const float* v = st.v;
+    if (LAY == LAY_K) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = tid + 256 * q;
+            const int row = f >> 2, kq = f & 3;
+            unsigned H0, M0, L0, H1, M1, L1;
+            split2(v[4 * q], v[4 * q + 1], H0, M0, L0);
+            split2(v[4 * q + 2], v[4 * q + 3], H1, M1, L1);
+            __bf16* dst = S + s_off(row, kq >> 1) + ((kq & 1) << 2);
+            *reinterpret_cast<uint2*>(dst) = make_uint2(H0, H1);
+            *reinterpret_cast<uint2*>(dst + SPLANE) = make_uint2(M0, M1);
+            *reinterpret_cast<uint2*>(dst + 2 * SPLANE) = make_uint2(L0, L1);
+        }
+    } else {
+        const int kp = tid & 7, mq = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (mq << 2) + i;
+            unsigned H, M, L;
+            split2(v[i], v[4 + i], H, M, L);                      // k = 2kp (low half), 2kp + 1 (high half)
+            __bf16* dst = S + s_off(row, kp >> 2) + ((kp & 3) << 1);
+            *reinterpret_cast<unsigned*>(dst) = H;
+            *reinterpret_cast<unsigned*>(dst + SPLANE) = M;
+            *reinterpret_cast<unsigned*>(dst + 2 * SPLANE) = L;
+        }
+    }
+}
+
+#ifndef BTVAE_SPLIT_PD
+#define BTVAE_SPLIT_PD 2          // k-tiles in flight in registers ahead of the one being multiplied
+#endif
+#ifndef BTVAE_SPLIT_VPM
+#define BTVAE_SPLIT_VPM 5         // vector instructions of the split scheduled behind each MFMA
+#endif
+#ifndef BTVAE_SPLIT_WG
+#define BTVAE_SPLIT_WG 2          // workgroups per CU the register budget is set for
+#endif
+
+template <int AL, int BL, int EPI>
+__global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const GemmArgs p) {
+    constexpr int PD = BTVAE_SPLIT_PD;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2][2][3 * SPLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = p.tiles_m * p.tiles_n;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nk = kend > kbeg ? (kend - kbeg + SBK - 1) / SBK : 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // k-tile j of this workgroup into a register set (no-op past the last tile; full tiles need no predicates)
+    auto fetch = [&](int j, SStage& a, SStage& b) {
+        if (j >= nk) return;
+        const int k0 = kbeg + j * SBK;
+        if (k0 + SBK <= kend) {
+            s_g2r<AL, true>(p.A, p.lda, m0, p.M, k0, kend, tid, a);
+            s_g2r<BL, true>(p.B, p.ldb, n0, p.N, k0, kend, tid, b);
+        } else {
+            s_g2r<AL, false>(p.A, p.lda, m0, p.M, k0, kend, tid, a);
+            s_g2r<BL, false>(p.B, p.ldb, n0, p.N, k0, kend, tid, b);
+        }
+    };
+
+    // Register sets: tile j (j >= 1) travels in set j % PD.  Tile 0 goes straight to LDS through set 0.
+    SStage sa[PD], sb[PD];
+    if (nk > 0) {
+        fetch(0, sa[0], sb[0]);
+        s_r2s<AL>(smem[0][0], tid, sa[0]);
+        s_r2s<BL>(smem[0][1], tid, sb[0]);
+    }
+#pragma unroll
+    for (int j = 1; j <= PD; ++j) fetch(j, sa[j % PD], sb[j % PD]);
+    __syncthreads();
+
+    // fragment offsets of this lane (same in every plane and buffer)
+    int oa[2], ob[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { oa[i] = s_off(wr * 64 + i * 32 + li, lh); ob[i] = s_off(wc * 64 + i * 32 + li, lh); }
+
+    auto tile_mma = [&](const __bf16* As, const __bf16* Bs) {
+        sbf16x8 a[3][2], b[3][2];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[pl][i] = *reinterpret_cast<const sbf16x8*>(As + pl * SPLANE + oa[i]);
+                b[pl][i] = *reinterpret_cast<const sbf16x8*>(Bs + pl * SPLANE + ob[i]);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {      // small terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    // Iteration t: multiply tile t from LDS, publish tile t+1 from its register set, refill that set with tile
+    // t+1+PD.  A load therefore has PD iterations of MFMA work (of the resident workgroups) to land.
+    // Steady state (every tile touched is a full one): straight-line code, with the split's vector instructions and
+    // LDS stores scheduled into the shadow of the 32-cycle MFMAs.
+    const int nfull = (kend - kbeg) / SBK;
+    int t0 = 0;
+    for (; t0 + 2 * PD < nfull; t0 += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const int t = t0 + u;
+            const int cur = t & 1;
+            tile_mma(smem[cur][0], smem[cur][1]);
+            s_r2s<AL>(smem[cur ^ 1][0], tid, sa[(u + 1) % PD]);
+            s_r2s<BL>(smem[cur ^ 1][1], tid, sb[(u + 1) % PD]);
+            const int k0 = kbeg + (t + 1 + PD) * SBK;
+            s_g2r<AL, true>(p.A, p.lda, m0, p.M, k0, kend, tid, sa[(u + 1) % PD]);
+            s_g2r<BL, true>(p.B, p.ldb, n0, p.N, k0, kend, tid, sb[(u + 1) % PD]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);          // fragment reads
+#pragma unroll
+            for (int k = 0; k < 24; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, BTVAE_SPLIT_VPM, 0);   // a few vector instructions
+                if (k & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // an LDS store
+            }
+            __syncthreads();
+        }
+    }
+    // Tail (and short reductions): same steps with bounds checks.
+    for (; t0 < nk; t0 += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const int t = t0 + u;
+            if (t < nk) {
+                const int cur = t & 1;
+                tile_mma(smem[cur][0], smem[cur][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < nk) {
+                    s_r2s<AL>(smem[cur ^ 1][0], tid, sa[(u + 1) % PD]);
+                    s_r2s<BL>(smem[cur ^ 1][1], tid, sb[(u + 1) % PD]);
+                }
+                fetch(t + 1 + PD, sa[(u + 1) % PD], sb[(u + 1) % PD]);
+                __syncthreads();
+            }
+        }
+    }
+
+    gemm_epilogue<EPI>(p, acc, reinterpret_cast<float*>(&smem[0][0][0]), m0, n0, tile_m);
+}
+
+}  // namespace btvae_gemm
