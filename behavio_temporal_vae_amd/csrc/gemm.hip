@@ -142,45 +142,6 @@ __device__ __forceinline__ float4 frag(const float* S, int rc, int g, int lh) {
 }
 
 
-// ---- fp32 products on the bf16 matrix pipe ("split" mode) -----------------------------------------------------
-// An fp32 value is the exact sum of three bf16 values h + m + l (8 significant bits each, taken by truncation).
-// a*b = sum of nine bf16 x bf16 products, each exact in fp32; the six largest (hh, hm, mh, mm, hl, lh) are issued
-// as v_mfma_f32_32x32x16_bf16 with fp32 accumulation, the three dropped ones are below 2^-21 of |a*b|.  Six bf16
-// MFMAs of 16 k cost 192 matrix-pipe cycles where eight fp32 MFMAs of 2 k cost 512.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// eight consecutive k of row/column rc for lane half lh (k = 8*lh .. 8*lh+7) of a BK=16 tile
-template <int LAY>
-__device__ __forceinline__ void frag8(const float* S, int rc, int lh, float (&v)[8]) {
-    if (LAY == LAY_K) {
-        const float4 p = *reinterpret_cast<const float4*>(S + rc * LDK + lh * 8);
-        const float4 q = *reinterpret_cast<const float4*>(S + rc * LDK + lh * 8 + 4);
-        v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
-    } else {
-        const float* q = S + (lh * 8) * LDM + rc;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = q[j * LDM];
-    }
-}
-
-__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-    unsigned H[4], M[4], L[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const float x0 = v[2 * p], x1 = v[2 * p + 1];
-        const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-        const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
-        const unsigned s0 = __float_as_uint(r0), s1 = __float_as_uint(r1);
-        const float l0 = r0 - __uint_as_float(s0 & 0xFFFF0000u), l1 = r1 - __uint_as_float(s1 & 0xFFFF0000u);
-        H[p] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);     // (high half of x1, high half of x0)
-        M[p] = __builtin_amdgcn_perm(s1, s0, 0x07060302u);
-        L[p] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
-    }
-    hi = __builtin_bit_cast(bf16x8, make_uint4(H[0], H[1], H[2], H[3]));
-    mid = __builtin_bit_cast(bf16x8, make_uint4(M[0], M[1], M[2], M[3]));
-    lo = __builtin_bit_cast(bf16x8, make_uint4(L[0], L[1], L[2], L[3]));
-}
-
 #ifndef BTVAE_GEMM_NBUF
 #define BTVAE_GEMM_NBUF 2     // LDS buffers per operand: 1 = 36 KB per workgroup (3 workgroups per CU), 2 = 72 KB (2 per CU)
 #endif
@@ -189,9 +150,8 @@ constexpr int NBUF = BTVAE_GEMM_NBUF;
 #define BTVAE_GEMM_MINWG ((BTVAE_GEMM_NBUF == 1 || BTVAE_GEMM_BK == 16) ? 3 : 2)   // workgroups per CU the register budget is set for
 #endif
 
-template <int AL, int BL, int EPI, bool VEC, bool SPLIT = false>
+template <int AL, int BL, int EPI, bool VEC>
 __global__ __launch_bounds__(256, BTVAE_GEMM_MINWG) void gemm_f32_mfma(const GemmArgs p) {
-    static_assert(!SPLIT || BK == 16, "split mode consumes a k-tile as one 16-deep bf16 MFMA step");
     __shared__ __attribute__((aligned(16))) float smem[NBUF][2][TILE_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
@@ -242,29 +202,6 @@ __global__ __launch_bounds__(256, BTVAE_GEMM_MINWG) void gemm_f32_mfma(const Gem
                 acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[rb].w, bg[cb].w, acc[rb][cb], 0, 0, 0);
             }
     };
-    // split mode: the whole 16-deep tile in one step of 24 bf16 MFMAs, small terms first
-    auto split_tile = [&](const float* As, const float* Bs) {
-        bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float v[8];
-            frag8<AL>(As, wr * 64 + i * 32 + li, lh, v);
-            split8(v, ah[i], am[i], al[i]);
-            frag8<BL>(Bs, wc * 64 + i * 32 + li, lh, v);
-            split8(v, bh[i], bm[i], bl[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-            }
-    };
     auto load_group = [&](const float* As, const float* Bs, int g, float4 (&ag)[2], float4 (&bg)[2]) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) ag[rb] = frag<AL>(As, wr * 64 + rb * 32 + li, g, lh);
@@ -286,18 +223,14 @@ __global__ __launch_bounds__(256, BTVAE_GEMM_MINWG) void gemm_f32_mfma(const Gem
         __builtin_amdgcn_sched_barrier(0);   // loads first, so the whole tile's MFMAs cover their latency
         const float* As = smem[cur][0];
         const float* Bs = smem[cur][1];
-        if (SPLIT) {
-            split_tile(As, Bs);
-        } else {
-            float4 a0[2], b0[2], a1[2], b1[2];
-            load_group(As, Bs, 0, a0, b0);
+        float4 a0[2], b0[2], a1[2], b1[2];
+        load_group(As, Bs, 0, a0, b0);
 #pragma unroll
-            for (int g = 0; g < NG; g += 2) {
-                load_group(As, Bs, g + 1, a1, b1);
-                mma_group(a0, b0);
-                if (g + 2 < NG) load_group(As, Bs, g + 2, a0, b0);
-                mma_group(a1, b1);
-            }
+        for (int g = 0; g < NG; g += 2) {
+            load_group(As, Bs, g + 1, a1, b1);
+            mma_group(a0, b0);
+            if (g + 2 < NG) load_group(As, Bs, g + 2, a0, b0);
+            mma_group(a1, b1);
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the LDS publish (and its wait on the loads) after the MFMAs
         if (NBUF == 2) {
@@ -315,16 +248,12 @@ __global__ __launch_bounds__(256, BTVAE_GEMM_MINWG) void gemm_f32_mfma(const Gem
         const int cur = NBUF == 2 ? (t & 1) : 0;
         const float* As = smem[cur][0];
         const float* Bs = smem[cur][1];
-        if (SPLIT) {
-            split_tile(As, Bs);         // the staging zero-fills past kend
-        } else {
-            const int krem = kend - (kbeg + t * BK);
-            const int ngroups = krem >= BK ? NG : (krem + 7) >> 3;
-            for (int g = 0; g < ngroups; ++g) {
-                float4 ag[2], bg[2];
-                load_group(As, Bs, g, ag, bg);
-                mma_group(ag, bg);
-            }
+        const int krem = kend - (kbeg + t * BK);
+        const int ngroups = krem >= BK ? NG : (krem + 7) >> 3;
+        for (int g = 0; g < ngroups; ++g) {
+            float4 ag[2], bg[2];
+            load_group(As, Bs, g, ag, bg);
+            mma_group(ag, bg);
         }
         __syncthreads();
     }

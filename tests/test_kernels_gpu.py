@@ -19,6 +19,15 @@ def dev():
     return d
 
 
+@pytest.fixture(params=["fp32", "fp32_split"])
+def gemm_mode(request):
+    """Both fp32-accurate precisions of the Linear products: the fp32 MFMA instruction and the exact three-way bf16
+    split on the bf16 matrix pipe.  Same tolerances for both."""
+    nv.set_gemm_precision(request.param)
+    yield request.param
+    nv.set_gemm_precision("fp32")
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale)
@@ -37,7 +46,7 @@ P = nv.ptr
 
 
 @pytest.mark.parametrize("M,K,N", [(300, 52, 1000), (256, 1000, 1000), (129, 40, 72), (64, 7, 5)])
-def test_linear_relu_stats(dev, M, K, N):
+def test_linear_relu_stats(dev, gemm_mode, M, K, N):
     X, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3, scale=0.1)
     Xd, Wd, bd = (t.float().to(dev) for t in (X, W, b))
     Y = torch.empty(M, N, device=dev)
@@ -56,7 +65,7 @@ def test_linear_relu_stats(dev, M, K, N):
     close(rv, 0.9 + 0.1 * yr.var(0, unbiased=True), 2e-5, 0, "running_var")
 
 
-def test_linear_relu_affine_and_head(dev):
+def test_linear_relu_affine_and_head(dev, gemm_mode):
     M, K, N = 200, 96, 100
     X, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.3), rnd(N, seed=3)
     sc, sh, R = rnd(N, seed=4), rnd(N, seed=5), rnd(M, N, seed=6)
@@ -90,7 +99,7 @@ def test_linear_relu_affine_and_head(dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 1000, 52), (4096, 100, 1000), (130, 48, 1000), (70, 9, 33)])
-def test_dgrad_wgrad(dev, M, N, K):
+def test_dgrad_wgrad(dev, gemm_mode, M, N, K):
     dY, W, X, R = rnd(M, N, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(M, K, seed=3), rnd(M, K, seed=4)
     d = [t.float().to(dev) for t in (dY, W, X, R)]
     c = [t.cpu().double() for t in d]
