@@ -42,9 +42,10 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X fp32 matrix peak (v_mfma_f32_32x32x2_f
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X bf16 dense matrix peak (v_mfma_f32_32x32x16_bf16, 1024 FLOP/clk/SIMD)
 SPLIT_TERMS = 6                  # bf16 MFMAs issued per fp32 product in the split mode
 # HBM-side bytes of one launch of the dominant kernel (M=65536, N=K=1000) from PMC passes kept under profiles/
-DOMINANT_KERNEL_HBM_BYTES = 2 * 324658 * 1024 + 304764 * 1024
+DOMINANT_KERNEL_HBM_BYTES = {"fp32": 2 * 324658 * 1024 + 304764 * 1024, "fp32_split": 2 * 367599 * 1024 + 331523 * 1024}
 
 
+KERNEL_NAME = {"fp32_split": "gemm_split_mfma", "fp32": "gemm_f32_mfma", "bf16": "gemm_bf16_mfma"}
 PRECISION_NOTE = {
     "fp32_split": "Linear products: fp32 operands as exact 3-way bf16 splits, 6 bf16 MFMAs per product with fp32 accumulation; "
                   "error against fp64 at or below the fp32 MFMA instruction's (tools/gemm_accuracy.py)",
@@ -281,11 +282,11 @@ def main():
                        "gemm_precision": main_precision, "global_batch": world * B,
                        "per_gpu_batch": B, "num_mc_samples": S, "input_dim": D, "cond_dim": C, "latent_dim": 48, "hidden": 1000,
                        "vocab": 100, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_f32_mfma<k-contig,k-contig,relu+stats,{main_precision}> M={S * B} N=K=1000 (decoder hidden Linear forward)",
+            "roofline": {"bound": "mfma", "kernel": f"{KERNEL_NAME[main_precision]}<k-contig,k-contig,relu+stats> M={S * B} N=K=1000 (decoder hidden Linear forward)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": peak_note,
                          "fp32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                          "flops_per_launch": dom_fl, "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
-                         "traffic": DOMINANT_KERNEL_HBM_BYTES if (S * B == 65536) else None,   # same loads/stores in both fp32 modes
+                         "traffic": DOMINANT_KERNEL_HBM_BYTES.get(main_precision) if (S * B == 65536) else None,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this kernel at this shape, separate passes: profiles/r1_gemm_fwd_pmc.md (not collected live)",
                          "algorithmic_bytes": 4.0 * (S * B * 1000 + 1000 * 1000 + S * B * 1000),
                          "fwd_family_tflops": fwd_fl / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else None,
