@@ -275,8 +275,8 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 std::atomic<int> g_precision{0};   // 0: fp32 MFMA, 1: bf16 operands, 2: fp32 operands as three bf16 pieces (Linear layers only)
 
-// `reduced_ok`: this product may run with bf16 operands when that mode is selected (Linear fwd/dgrad/wgrad);
-// the covariance products of the likelihood always run in fp32.  On return a.kchunk holds the split length used.
+// `reduced_ok`: this product may run with bf16-ROUNDED operands when that mode is selected (Linear fwd/dgrad/wgrad);
+// the covariance products of the likelihood never do.  The split mode is fp32-accurate and applies to every product.  On return a.kchunk holds the split length used.
 template <int AL, int BL, int EPI>
 int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduced_ok = false) {
     BTVAE_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "%s: empty problem M=%d N=%d K=%d", what, a.M, a.N, a.K);
@@ -292,7 +292,7 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     if (splits < 1) splits = 1;
     const int prec = g_precision.load(std::memory_order_relaxed);
     const bool bf16 = reduced_ok && prec == 1 && a.a_vec && a.b_vec;
-    const bool split = reduced_ok && prec == 2 && a.a_vec && a.b_vec;
+    const bool split = prec == 2 && a.a_vec && a.b_vec;          // fp32-accurate: every product may use it
     const int bk = bf16 ? HBK : split ? SBK : BK;
     a.kchunk = (((a.K + splits - 1) / splits) + bk - 1) / bk * bk;
     splits = (a.K + a.kchunk - 1) / a.kchunk;

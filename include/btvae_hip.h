@@ -25,9 +25,11 @@ int btvae_prof_collect(double* ms, double* flops, double* bytes, long long* laun
 /* Before btvae_prof_collect: the launches of one family with the largest FLOP count (its dominant shape). */
 int btvae_prof_dominant(int kind, double* ms, double* flops_per_launch, long long* count);
 
-/* Operand precision of the Linear-layer products (btvae_linear_*_fwd, _dgrad, _wgrad): 0 = fp32 MFMA (default,
- * the precision torch.nn.Linear runs at in the reference, src/submodels.py:15-17), 1 = operands rounded to bf16
- * on the way into LDS with fp32 accumulation.  Process-wide.  The covariance products stay fp32. */
+/* Operand precision of the matrix products.  0 = the fp32 MFMA instruction (default of the library; the precision
+ * torch.nn.Linear runs at in the reference, src/submodels.py:15-17).  1 = operands of the Linear-layer products
+ * (btvae_linear_*_fwd, _dgrad, _wgrad) rounded to bf16 on the way into LDS, fp32 accumulation; the covariance products
+ * stay fp32.  2 = every product fp32-accurate on the bf16 matrix pipe: operands split exactly into three bf16 pieces,
+ * six bf16 MFMAs per product (error against fp64 at or below mode 0's).  Process-wide. */
 int btvae_set_gemm_precision(int mode);
 int btvae_get_gemm_precision(void);
 
