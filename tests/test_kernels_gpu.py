@@ -206,7 +206,7 @@ def test_reparam_kl(dev, threeD):
     assert abs(e1.mean().item()) < 0.05 and abs(e1.std().item() - 1) < 0.05
 
 
-@pytest.mark.parametrize("D,V,rows,B", [(48, 100, 301, 43), (6, 9, 50, 10), (24, 100, 130, 130)])
+@pytest.mark.parametrize("D,V,rows,B", [(48, 100, 301, 43), (6, 9, 50, 10), (24, 100, 130, 130), (64, 70, 37, 37), (2, 3, 5, 1), (33, 40, 4, 4)])
 def test_dictgauss_mvn(dev, D, V, rows, B):
     U = rnd(D, V, seed=1)
     sig = (rnd(rows, V, seed=2).abs() * 0.3 + 1e-3).clamp(max=0.62)
@@ -320,14 +320,17 @@ def test_clip_adam(dev):
         close(p[:n], pr.detach(), 1e-6, 2e-7, f"params step {step}")
 
 
-def test_cond_mvn(dev):
-    rows, D, Uc = 70, 48, 24
+@pytest.mark.parametrize("rows,D,obs", [(70, 48, list(range(0, 12)) + list(range(36, 48))),     # a non-suffix window
+                                        (5, 64, list(range(1, 64, 2))),                          # largest dimension, interleaved
+                                        (9, 7, [6]),                                             # one observed coordinate
+                                        (3, 24, list(range(23)))])                               # one unobserved coordinate
+def test_cond_mvn(dev, rows, D, obs):
+    Uc = D - len(obs)
     NP = D * (D + 1) // 2
     A = rnd(rows, D, D, seed=1) * 0.3
     Sigma = A @ A.transpose(-1, -2) + torch.eye(D, dtype=torch.float64) * 0.01
     Sigma = Sigma.float().double()
     mu, x, eps = rnd(rows, D, seed=2).float(), rnd(rows, D, seed=3).float(), rnd(rows, Uc, seed=4).float()
-    obs = list(range(0, 12)) + list(range(36, 48))      # a non-suffix window
     un = [i for i in range(D) if i not in obs]
     tri = torch.tril_indices(D, D)
     Sp = Sigma[:, tri[0], tri[1]].float().to(dev)
