@@ -289,6 +289,9 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     // the vector path treats every 4-float chunk as all-or-nothing, so the contiguous extent must be a multiple of 4
     a.a_vec = (a.lda % 4 == 0) && aligned16(a.A) && ((AL == LAY_K ? a.K : a.M) % 4 == 0);
     a.b_vec = (a.ldb % 4 == 0) && aligned16(a.B) && ((BL == LAY_K ? a.K : a.N) % 4 == 0);
+    a.c_vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && aligned16(a.C) && (a.slab_stride % 4 == 0) &&
+              (!a.R || (a.ldr % 4 == 0 && aligned16(a.R))) && (!a.C2 || aligned16(a.C2)) && (!a.C3 || aligned16(a.C3)) &&
+              (EPI != EPI_MUL || (a.lde % 4 == 0 && aligned16(a.E1) && aligned16(a.E2)));
     if (splits < 1) splits = 1;
     const int prec = g_precision.load(std::memory_order_relaxed);
     const bool bf16 = reduced_ok && prec == 1 && a.a_vec && a.b_vec;

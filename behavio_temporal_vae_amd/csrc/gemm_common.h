@@ -27,6 +27,7 @@ struct GemmArgs {
     const float* E1; const float* E2; int lde;  // EPI_MUL
     int act; float lo, hi;      // EPI_HEAD
     int a_vec, b_vec;
+    int c_vec;                  // outputs / add-ins allow 16-byte row accesses: epilogue staged through LDS
     int tiles_m, tiles_n;
 };
 
@@ -34,7 +35,7 @@ __device__ __forceinline__ float softplus5(float x) { return x > 5.f ? x : log1p
 
 // `red` is LDS scratch of at least 6*128 floats that no wave still reads as a tile.
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2][2], float* red, int m0, int n0, int tile_m) {
+__device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x16 (&acc)[2][2], float* red, int m0, int n0, int tile_m) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -160,6 +161,151 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2
             p.stats[((size_t)tile_m * 2 + 1) * p.N + n0 + tid] = m2;
         }
     }
+}
+
+// ---- epilogue staged through LDS ---------------------------------------------------------------------------------
+// The accumulator image puts one column per lane, so storing it directly costs 64 four-byte stores per thread (and as
+// many loads for an add-in).  Here each half of the 128x128 tile (the 64 rows of accumulator block rb of both wave
+// rows) goes through a [64][132] fp32 LDS image and leaves as 16-byte accesses: 8 per thread and output.
+// `lds` must hold 64*132 + 6*128 floats (36 KiB) that no wave still reads as a tile.
+constexpr int EPL = 132;
+
+__device__ __forceinline__ float4 ld4(const float* q) { return *reinterpret_cast<const float4*>(q); }
+__device__ __forceinline__ void st4(float* q, const float4 v) { *reinterpret_cast<float4*>(q) = v; }
+
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[2][2], float* lds, int m0, int n0, int tile_m) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    float* red = lds + 64 * EPL;
+    float bias[2], sc[2], sh[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int col = n0 + wc * 64 + cb * 32 + li;
+        const bool ok = col < p.N;
+        bias[cb] = (EPI == EPI_BIAS || EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE || EPI == EPI_HEAD) && ok && p.bias ? p.bias[col] : 0.f;
+        sc[cb] = (EPI == EPI_RELU_AFFINE && ok && p.scale) ? p.scale[col] : 1.f;
+        sh[cb] = (EPI == EPI_RELU_AFFINE && ok && p.shift) ? p.shift[col] : 0.f;
+    }
+    float* Cz = p.C + (size_t)blockIdx.z * p.slab_stride;
+    // column statistics (EPI_RELU_STATS): shifted sums per lane over its rows of both halves
+    float st_k[2] = {0.f, 0.f}, st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f}, st_c[2] = {0.f, 0.f};
+    bool have[2] = {false, false};
+
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        // registers -> LDS image; local row = wr*32 + (r&3) + 8(r>>2) + 4*lh
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int col = n0 + wc * 64 + cb * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[rb][cb][r];
+                if (EPI == EPI_BIAS || EPI == EPI_HEAD) v += bias[cb];
+                if (EPI == EPI_RELU_STATS) {
+                    v = fmaxf(v + bias[cb], 0.f);
+                    const int row = m0 + (lr >> 5) * 64 + rb * 32 + (lr & 31);
+                    if (row < p.M && col < p.N) {
+                        if (!have[cb]) { st_k[cb] = v; have[cb] = true; }
+                        const float d = v - st_k[cb];
+                        st_s[cb] += d; st_q[cb] = fmaf(d, d, st_q[cb]); st_c[cb] += 1.f;
+                    }
+                }
+                if (EPI == EPI_RELU_AFFINE) v = fmaxf(v + bias[cb], 0.f) * sc[cb] + sh[cb];
+                lds[lr * EPL + wc * 64 + cb * 32 + li] = v;
+            }
+        }
+        __syncthreads();
+        // LDS image -> global, 16 bytes per lane: thread t handles columns 4*(t&31).. of local rows (t>>5) + 8j
+        const int c4 = (tid & 31) << 2;
+        const int col = n0 + c4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lr = (tid >> 5) + 8 * j;
+            const int row = m0 + (lr >> 5) * 64 + rb * 32 + (lr & 31);
+            if (row < p.M && col < p.N) {          // N % 4 == 0 on this path: a 4-column group is in or out as a whole
+                float4 v = ld4(lds + lr * EPL + c4);
+                const size_t o = (size_t)row * p.ldc + col;
+                if (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_RELU_AFFINE) {
+                    if (p.R) { const float4 q = ld4(p.R + (size_t)row * p.ldr + col); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+                    st4(Cz + o, v);
+                } else if (EPI == EPI_RELU_STATS) {
+                    st4(Cz + o, v);
+                } else if (EPI == EPI_MUL) {
+                    const size_t e = (size_t)row * p.lde + col;
+                    const float4 a = ld4(p.E1 + e), b = ld4(p.E2 + e);
+                    st4(Cz + o, make_float4(v.x * a.x * b.x, v.y * a.y * b.y, v.z * a.z * b.z, v.w * a.w * b.w));
+                } else if (EPI == EPI_HEAD) {
+                    const float raw[4] = {v.x, v.y, v.z, v.w};
+                    float val[4], df[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (p.act == 0) {            // clamp
+                            val[e] = fminf(fmaxf(raw[e], p.lo), p.hi);
+                            df[e] = (raw[e] >= p.lo && raw[e] <= p.hi) ? 1.f : 0.f;
+                        } else if (p.act == 1) {     // clamp(softplus(raw; threshold 5))
+                            const float sp = softplus5(raw[e]);
+                            val[e] = fminf(fmaxf(sp, p.lo), p.hi);
+                            df[e] = (sp >= p.lo && sp <= p.hi) ? (raw[e] > 5.f ? 1.f : 1.f / (1.f + expf(-raw[e]))) : 0.f;
+                        } else {                     // clamp(relu(raw))
+                            const float rl = fmaxf(raw[e], 0.f);
+                            val[e] = fminf(fmaxf(rl, p.lo), p.hi);
+                            df[e] = (raw[e] > 0.f && rl >= p.lo && rl <= p.hi) ? 1.f : 0.f;
+                        }
+                    }
+                    st4(Cz + o, make_float4(val[0], val[1], val[2], val[3]));
+                    if (p.C2) st4(p.C2 + o, make_float4(df[0], df[1], df[2], df[3]));
+                    if (p.C3) st4(p.C3 + o, make_float4(val[0] * val[0], val[1] * val[1], val[2] * val[2], val[3] * val[3]));
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (EPI == EPI_RELU_STATS) {
+        // per lane (count, mean, M2) -> merge lane halves -> merge the two wave rows through LDS -> one thread per column
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            float cnt = st_c[cb], mean = 0.f, m2 = 0.f;
+            if (cnt > 0.f) { mean = st_k[cb] + st_s[cb] / cnt; m2 = fmaxf(st_q[cb] - st_s[cb] * st_s[cb] / cnt, 0.f); }
+            const float on = __shfl_xor(cnt, 32, 64), om = __shfl_xor(mean, 32, 64), o2 = __shfl_xor(m2, 32, 64);
+            const float n = cnt + on;
+            if (n > 0.f) {
+                const float dlt = om - mean;
+                m2 = m2 + o2 + dlt * dlt * (cnt * on / n);
+                mean = (cnt * mean + on * om) / n;
+            }
+            if (lh == 0) {
+                const int c = wc * 64 + cb * 32 + li;
+                red[(wr * 3 + 0) * 128 + c] = n;
+                red[(wr * 3 + 1) * 128 + c] = mean;
+                red[(wr * 3 + 2) * 128 + c] = m2;
+            }
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            const float na = red[0 * 128 + tid], ma = red[1 * 128 + tid], qa = red[2 * 128 + tid];
+            const float nb = red[3 * 128 + tid], mb = red[4 * 128 + tid], qb = red[5 * 128 + tid];
+            const float n = na + nb;
+            float mean = ma, m2 = qa;
+            if (nb > 0.f) {
+                const float dlt = mb - ma;
+                m2 = qa + qb + dlt * dlt * (na * nb / n);
+                mean = (na * ma + nb * mb) / n;
+            }
+            p.stats[((size_t)tile_m * 2 + 0) * p.N + n0 + tid] = mean;
+            p.stats[((size_t)tile_m * 2 + 1) * p.N + n0 + tid] = m2;
+        }
+    }
+}
+
+// `lds`: at least 36 KiB of LDS that no wave still reads as a tile
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2][2], float* lds, int m0, int n0, int tile_m) {
+    if (p.c_vec) gemm_epilogue_staged<EPI>(p, acc, lds, m0, n0, tile_m);
+    else         gemm_epilogue_direct<EPI>(p, acc, lds, m0, n0, tile_m);
 }
 
 }  // namespace btvae_gemm
