@@ -10,41 +10,65 @@ namespace {
 
 constexpr int STRIP_COLS = 256;   // columns per workgroup: 64 lanes x float4
 
+// Sum over the lanes that hold the same column group (lane bits 3..5) of a wave.
+__device__ __forceinline__ double group_sum8(double v) {
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 // ---- train-mode statistics: merge the per-row-tile (mean, M2) partials of the GEMM epilogue ----
+// A workgroup owns 8 groups of VEC columns; thread (group g = tid & 7, part = tid >> 3) takes every 32nd tile, so a
+// 512-tile merge is 16 independent loads per thread.  With n_t rows in tile t the merged moments are
+//   mean = sum n_t mean_t / n,   M2 = sum M2_t + sum n_t mean_t^2 - n mean^2
+// accumulated in fp64 (inputs are fp32, so the subtraction keeps ~29 bits more than they carry).
+template <int VEC>
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partials, int ntiles, int tile_rows, int M, int N,
                                                                 float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                                                 float* __restrict__ m2_out,
                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                 float momentum, float eps) {
-    // 32 columns x 8 tile-groups per workgroup: each thread Chan-merges every 8th tile in fp64, the 8 partial
-    // triples of a column are merged through LDS.
-    __shared__ double sh[3][8][32];
-    const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    if (c < N) {
-        for (int t = part; t < ntiles; t += 8) {
+    __shared__ double sh[3][4][8 * VEC];
+    const int g = threadIdx.x & 7, part = threadIdx.x >> 3, w = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 8 + g) * VEC;
+    double s1[VEC], s2[VEC], q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s1[j] = 0.0; s2[j] = 0.0; q[j] = 0.0; }
+    if (c0 < N) {
+#pragma unroll 4
+        for (int t = part; t < ntiles; t += 32) {
             const double nb = (double)min(tile_rows, M - t * tile_rows);
-            const double mb = partials[((size_t)t * 2 + 0) * N + c];
-            const double qb = partials[((size_t)t * 2 + 1) * N + c];
-            const double tot = n + nb, d = mb - mean;
-            m2 += qb + d * d * (n * nb / tot);
-            mean += d * (nb / tot);
-            n = tot;
+            float mb[VEC], qb[VEC];
+            if (VEC == 4) {
+                const float4 a = *reinterpret_cast<const float4*>(partials + ((size_t)t * 2 + 0) * N + c0);
+                const float4 b = *reinterpret_cast<const float4*>(partials + ((size_t)t * 2 + 1) * N + c0);
+                mb[0] = a.x; mb[VEC > 1 ? 1 : 0] = a.y; mb[VEC > 2 ? 2 : 0] = a.z; mb[VEC > 3 ? 3 : 0] = a.w;
+                qb[0] = b.x; qb[VEC > 1 ? 1 : 0] = b.y; qb[VEC > 2 ? 2 : 0] = b.z; qb[VEC > 3 ? 3 : 0] = b.w;
+            } else {
+                mb[0] = partials[((size_t)t * 2 + 0) * N + c0];
+                qb[0] = partials[((size_t)t * 2 + 1) * N + c0];
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const double m = (double)mb[j];
+                s1[j] += nb * m; s2[j] += nb * m * m; q[j] += (double)qb[j];
+            }
         }
     }
-    sh[0][part][cl] = n; sh[1][part][cl] = mean; sh[2][part][cl] = m2;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        s1[j] = group_sum8(s1[j]); s2[j] = group_sum8(s2[j]); q[j] = group_sum8(q[j]);
+        if ((threadIdx.x & 63) < 8) { sh[0][w][g * VEC + j] = s1[j]; sh[1][w][g * VEC + j] = s2[j]; sh[2][w][g * VEC + j] = q[j]; }
+    }
     __syncthreads();
-    if (part != 0 || c >= N) return;
-    for (int q = 1; q < 8; ++q) {
-        const double nb = sh[0][q][cl], mb = sh[1][q][cl], qb = sh[2][q][cl];
-        if (nb > 0.0) {
-            const double tot = n + nb, d = mb - mean;
-            m2 += qb + d * d * (n * nb / tot);
-            mean += d * (nb / tot);
-            n = tot;
-        }
-    }
+    const int cl = threadIdx.x;
+    const int c = blockIdx.x * 8 * VEC + cl;
+    if (cl >= 8 * VEC || c >= N) return;
+    const double n = (double)M;
+    const double a1 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
+    const double a2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+    const double aq = sh[2][0][cl] + sh[2][1][cl] + sh[2][2][cl] + sh[2][3][cl];
+    const double mean = a1 / n;
+    const double m2 = fmax(aq + (a2 - n * mean * mean), 0.0);
     const double var_b = m2 / n;
     mean_out[c] = (float)mean;
     if (invstd_out) invstd_out[c] = (float)(1.0 / sqrt(var_b + (double)eps));
@@ -158,26 +182,52 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
-// merge [nchunks][nvec][N] partial column sums in fp64 (32 columns x 8 chunk-groups per workgroup);
-// raw_k (if given) = sum, out_k (if given) (+)= sum
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partials, int nchunks, int nvec, int N,
+// merge [nchunks][NVEC][N] partial column sums in fp64; raw_k (if given) = sum, out_k (if given) (+)= sum.
+// Same thread layout as the statistics merge: 8 groups of VEC columns x 32 chunk-parts per workgroup.
+template <int VEC, int NVEC>
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partials, int nchunks, int N,
                                                               float* out0, float* out1, float* raw0, float* raw1, int accumulate) {
-    __shared__ double sh[8][32];
-    const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    for (int k = 0; k < nvec; ++k) {
-        double s = 0.0;
-        if (c < N) for (int t = part; t < nchunks; t += 8) s += partials[((size_t)t * nvec + k) * N + c];
-        sh[part][cl] = s;
-        __syncthreads();
-        if (part == 0 && c < N) {
-            for (int q = 1; q < 8; ++q) s += sh[q][cl];
-            float* o = k == 0 ? out0 : out1;
-            float* r = k == 0 ? raw0 : raw1;
-            if (r) r[c] = (float)s;
-            if (o) o[c] = accumulate ? o[c] + (float)s : (float)s;
+    __shared__ double sh[NVEC][4][8 * VEC];
+    const int g = threadIdx.x & 7, part = threadIdx.x >> 3, w = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 8 + g) * VEC;
+    double s[NVEC][VEC];
+#pragma unroll
+    for (int k = 0; k < NVEC; ++k)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s[k][j] = 0.0;
+    if (c0 < N) {
+#pragma unroll 4
+        for (int t = part; t < nchunks; t += 32) {
+#pragma unroll
+            for (int k = 0; k < NVEC; ++k) {
+                const float* src = partials + ((size_t)t * NVEC + k) * N + c0;
+                if (VEC == 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(src);
+                    s[k][0] += a.x; s[k][VEC > 1 ? 1 : 0] += a.y; s[k][VEC > 2 ? 2 : 0] += a.z; s[k][VEC > 3 ? 3 : 0] += a.w;
+                } else {
+                    s[k][0] += src[0];
+                }
+            }
         }
-        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < NVEC; ++k)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const double v = group_sum8(s[k][j]);
+            if ((threadIdx.x & 63) < 8) sh[k][w][g * VEC + j] = v;
+        }
+    __syncthreads();
+    const int cl = threadIdx.x;
+    const int c = blockIdx.x * 8 * VEC + cl;
+    if (cl >= 8 * VEC || c >= N) return;
+#pragma unroll
+    for (int k = 0; k < NVEC; ++k) {
+        const float v = (float)(sh[k][0][cl] + sh[k][1][cl] + sh[k][2][cl] + sh[k][3][cl]);
+        float* o = k == 0 ? out0 : out1;
+        float* r = k == 0 ? raw0 : raw1;
+        if (r) r[c] = v;
+        if (o) o[c] = accumulate ? o[c] + v : v;
     }
 }
 
@@ -297,6 +347,30 @@ inline bool vec4_ok(int N, const void* a, const void* b, const void* c, const vo
 
 inline int chunk_count(int M) { return std::max(1, std::min(256, (M + 63) / 64)); }
 
+inline bool part_vec4(int N, const void* p) { return N % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// one- or two-vector merge of strip partials
+void colsum_finalize(hipStream_t s, const float* partials, int nchunks, int nvec, int N, float* out0, float* out1, float* raw0,
+                     float* raw1, int accumulate) {
+    const bool v4 = part_vec4(N, partials);
+    const dim3 grid((N + (v4 ? 32 : 8) - 1) / (v4 ? 32 : 8)), block(256);
+    if (nvec == 2) {
+        if (v4) hipLaunchKernelGGL((colsum_finalize_kernel<4, 2>), grid, block, 0, s, partials, nchunks, N, out0, out1, raw0, raw1, accumulate);
+        else    hipLaunchKernelGGL((colsum_finalize_kernel<1, 2>), grid, block, 0, s, partials, nchunks, N, out0, out1, raw0, raw1, accumulate);
+    } else {
+        if (v4) hipLaunchKernelGGL((colsum_finalize_kernel<4, 1>), grid, block, 0, s, partials, nchunks, N, out0, out1, raw0, raw1, accumulate);
+        else    hipLaunchKernelGGL((colsum_finalize_kernel<1, 1>), grid, block, 0, s, partials, nchunks, N, out0, out1, raw0, raw1, accumulate);
+    }
+}
+
+void stats_finalize(hipStream_t s, const float* partials, int ntiles, int tile_rows, int M, int N, float* mean, float* invstd, float* m2,
+                    float* running_mean, float* running_var, float momentum, float eps) {
+    if (part_vec4(N, partials))
+        hipLaunchKernelGGL((bn_stats_finalize_kernel<4>), dim3((N + 31) / 32), dim3(256), 0, s, partials, ntiles, tile_rows, M, N, mean, invstd, m2, running_mean, running_var, momentum, eps);
+    else
+        hipLaunchKernelGGL((bn_stats_finalize_kernel<1>), dim3((N + 7) / 8), dim3(256), 0, s, partials, ntiles, tile_rows, M, N, mean, invstd, m2, running_mean, running_var, momentum, eps);
+}
+
 }  // namespace
 
 using namespace btvae;
@@ -310,8 +384,7 @@ BTVAE_API int btvae_bn_stats_finalize(const float* partials, int ntiles, int M, 
     BTVAE_REQUIRE(ntiles == (M + 127) / 128, "bn_stats_finalize: ntiles %d does not match M %d", ntiles, M);
     BTVAE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize: pass both running buffers or neither");
     ProfScope ps(PK_BN, (hipStream_t)stream, 0, 8.0 * ntiles * N);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, ntiles, 128, M, N,
-                       mean, invstd, (float*)nullptr, running_mean, running_var, momentum, eps);
+    stats_finalize((hipStream_t)stream, partials, ntiles, 128, M, N, mean, invstd, nullptr, running_mean, running_var, momentum, eps);
     return check_launch("bn_stats_finalize");
 }
 
@@ -321,8 +394,7 @@ BTVAE_API int btvae_bn_stats_local(const float* partials, int ntiles, int M, int
     BTVAE_REQUIRE(partials && local, "bn_stats_local: null pointer");
     BTVAE_REQUIRE(ntiles == (M + 127) / 128, "bn_stats_local: ntiles %d does not match M %d", ntiles, M);
     ProfScope ps(PK_BN, (hipStream_t)stream, 0, 8.0 * ntiles * N);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, ntiles, 128, M, N,
-                       local, (float*)nullptr, local + N, (float*)nullptr, (float*)nullptr, 0.f, 0.f);
+    stats_finalize((hipStream_t)stream, partials, ntiles, 128, M, N, local, nullptr, local + N, nullptr, nullptr, 0.f, 0.f);
     return check_launch("bn_stats_local");
 }
 
@@ -334,8 +406,7 @@ BTVAE_API int btvae_bn_stats_merge(const float* parts, int nparts, int rows_per_
     BTVAE_REQUIRE(parts && mean && invstd && nparts > 0 && rows_per_part > 0, "bn_stats_merge: bad argument");
     BTVAE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_merge: pass both running buffers or neither");
     ProfScope ps(PK_BN, (hipStream_t)stream, 0, 8.0 * nparts * N);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, parts, nparts, rows_per_part,
-                       nparts * rows_per_part, N, mean, invstd, (float*)nullptr, running_mean, running_var, momentum, eps);
+    stats_finalize((hipStream_t)stream, parts, nparts, rows_per_part, nparts * rows_per_part, N, mean, invstd, nullptr, running_mean, running_var, momentum, eps);
     return check_launch("bn_stats_merge");
 }
 
@@ -379,10 +450,10 @@ BTVAE_API int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mea
     // k=0 -> sum g (dbeta), k=1 -> sum g*xhat (dgamma); current-batch values go to the tail of the scratch
     float* cur_dbeta = scratch + (size_t)3 * chunks * N;
     float* cur_dgamma = cur_dbeta + N;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, p2, chunks, 2, N, dbeta, dgamma, cur_dbeta, cur_dgamma, accumulate);
+    colsum_finalize(s, p2, chunks, 2, N, dbeta, dgamma, cur_dbeta, cur_dgamma, accumulate);
     if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc, 1.f / (float)M);
     else    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc, 1.f / (float)M);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, p1, chunks, 1, N, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
+    colsum_finalize(s, p1, chunks, 1, N, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
     return check_launch("bn_relu_bwd");
 }
 
@@ -409,7 +480,7 @@ BTVAE_API int btvae_bn_relu_bwd_sums(const float* G, const float* Y, const float
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 2 + (keep ? 1.0 * M * N : 0.0));
     if (vec4_ok(N, G, Y, nullptr, keep)) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, scratch, M, N, rpc);
     else                                 hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, scratch, M, N, rpc);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, scratch, chunks, 2, N, dbeta, dgamma, sums, sums + N, accumulate);
+    colsum_finalize(s, scratch, chunks, 2, N, dbeta, dgamma, sums, sums + N, accumulate);
     return check_launch("bn_relu_bwd_sums");
 }
 
@@ -427,7 +498,7 @@ BTVAE_API int btvae_bn_relu_bwd_apply(const float* G, const float* Y, const floa
         hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, rpc, inv);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, rpc, inv);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, scratch, chunks, 1, N, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
+    colsum_finalize(s, scratch, chunks, 1, N, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
     return check_launch("bn_relu_bwd_apply");
 }
 
@@ -444,7 +515,7 @@ BTVAE_API int btvae_relu_bwd(const float* G, const float* Y, const unsigned char
         hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc, 1.f);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc, 1.f);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, scratch, chunks, 1, N, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
+    colsum_finalize(s, scratch, chunks, 1, N, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
     return check_launch("relu_bwd");
 }
 
@@ -461,6 +532,6 @@ BTVAE_API int btvae_colsum(const float* G, float* out, float* scratch, int M, in
         hipLaunchKernelGGL((colsum_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, scratch, M, N, rpc);
     else
         hipLaunchKernelGGL((colsum_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, scratch, M, N, rpc);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 31) / 32), dim3(256), 0, s, scratch, chunks, 1, N, out, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
+    colsum_finalize(s, scratch, chunks, 1, N, out, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
     return check_launch("colsum");
 }
