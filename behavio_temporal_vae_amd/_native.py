@@ -22,6 +22,7 @@ P, I, F, LL, ULL = c_void_p, c_int, c_float, c_longlong, c_ulonglong
 _SIGS = {
     "btvae_init": [I],
     "btvae_prof_enable": [I],
+    "btvae_prof_filter": [ctypes.c_uint, ctypes.c_double],
     "btvae_prof_collect": [P, P, P, P, I],
     "btvae_prof_dominant": [I, P, P, P],
     "btvae_set_gemm_precision": [I],
@@ -157,6 +158,13 @@ def get_gemm_precision() -> str:
 
 def prof_enable(on: bool):
     lib().btvae_prof_enable(1 if on else 0)
+
+
+def prof_filter(kinds=None, min_flops: float = 0.0):
+    """Time only the named families (None = all) and launches of at least ``min_flops`` FLOPs: every timed launch
+    costs two event records on its stream."""
+    mask = 0xFFFFFFFF if kinds is None else sum(1 << PROF_KINDS.index(k) for k in kinds)
+    lib().btvae_prof_filter(mask, float(min_flops))
 
 
 def prof_dominant(kind: str):

@@ -20,6 +20,8 @@ int set_error(const char* fmt, ...) {
 
 struct ProfRec { int kind; hipEvent_t e0, e1; double flops, bytes; };
 static bool g_prof_on = false;
+static unsigned g_kind_mask = ~0u;     // families that are timed while g_prof_on
+static double g_min_flops = 0.0;       // ... and only launches at or above this FLOP count
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_free;
 static std::mutex g_mu;
@@ -32,6 +34,7 @@ static hipEvent_t get_event() {
 
 void prof_begin(int kind, hipStream_t s, double flops, double bytes) {
     if (!g_prof_on) return;
+    if (!((g_kind_mask >> kind) & 1u) || flops < g_min_flops) return;
     std::lock_guard<std::mutex> lk(g_mu);
     ProfRec r{kind, get_event(), get_event(), flops, bytes};
     hipEventRecord(r.e0, s);
@@ -74,6 +77,16 @@ BTVAE_API int btvae_prof_enable(int on) {
     for (auto& r : g_recs) { g_free.push_back(r.e0); g_free.push_back(r.e1); }
     g_recs.clear();
     g_prof_on = on != 0;
+    return 0;
+}
+
+// Restrict event timing to the families in kind_mask (bit k = family k) and to launches of at least min_flops FLOPs.
+// Two event records bracket every timed launch and each costs a few microseconds of stream time, so a timed region
+// that should run undisturbed selects only the launches it wants measured.  (~0u, 0) times everything (the default).
+BTVAE_API int btvae_prof_filter(unsigned kind_mask, double min_flops) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_kind_mask = kind_mask;
+    g_min_flops = min_flops;
     return 0;
 }
 

@@ -21,6 +21,8 @@ int btvae_init(int device);
 /* Event timing per kernel family (0 gemm_fwd, 1 gemm_dgrad, 2 gemm_wgrad, 3 gemm_mvn, 4 bn, 5 mvn_rows,
  * 6 reduce, 7 optim); collect after a device synchronisation into arrays of 8. */
 int btvae_prof_enable(int on);
+/* Time only the families in kind_mask (bit k = family k) and launches of at least min_flops; (~0u, 0) = everything. */
+int btvae_prof_filter(unsigned kind_mask, double min_flops);
 int btvae_prof_collect(double* ms, double* flops, double* bytes, long long* launches, int n);
 /* Before btvae_prof_collect: the launches of one family with the largest FLOP count (its dominant shape). */
 int btvae_prof_dominant(int kind, double* ms, double* flops_per_launch, long long* count);
