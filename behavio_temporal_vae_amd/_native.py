@@ -38,16 +38,18 @@ _SIGS = {
     "btvae_bn_stats_finalize": [P, I, I, I, P, P, P, P, F, F, P],
     "btvae_bn_fold_eval": [P, P, P, P, F, P, P, I, P],
     "btvae_bn_apply_fwd": [P, P, P, P, P, P, P, F, P, I, I, P],
-    "btvae_bn_relu_bwd": [P, P, P, P, P, P, F, P, P, P, P, P, I, I, I, P],
-    "btvae_relu_bwd": [P, P, P, F, P, P, P, I, I, I, P],
+    "btvae_bn_relu_bwd": [P, P, P, P, P, P, F, P, P, P, P, P, P, I, I, I, P],
+    "btvae_relu_bwd": [P, P, P, F, P, P, P, P, I, I, I, P],
+    "btvae_bn_fold_linear": [P, P, P, P, P, P, P, P, P, P, I, I, P],
+    "btvae_linear_wgrad_affine": [P, P, I, P, P, P, P, P, LL, I, I, I, I, P],
     "btvae_bn_stats_local": [P, I, I, I, P, P],
     "btvae_bn_stats_merge": [P, I, I, I, P, P, P, P, F, F, P],
     "btvae_bn_relu_bwd_sums": [P, P, P, P, P, F, P, P, P, P, I, I, I, P],
-    "btvae_bn_relu_bwd_apply": [P, P, P, P, P, P, F, P, LL, P, P, P, I, I, I, P],
+    "btvae_bn_relu_bwd_apply": [P, P, P, P, P, P, F, P, LL, P, P, P, P, I, I, I, P],
     "btvae_dropout_keep_mask": [P, LL, F, ULL, ULL, P],
     "btvae_sample_error_update": [P, P, P, P, I, I, I, I, P],
     "btvae_dirichlet_sample": [P, P, P, I, I, I, I, I, ULL, ULL, P],
-    "btvae_colsum": [P, P, P, I, I, I, P],
+    "btvae_colsum": [P, P, P, P, I, I, I, P],
     "btvae_reparam_kl_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, ULL, ULL, P],
     "btvae_reparam_kl_bwd": [P, P, P, P, P, P, P, P, I, I, I, I, F, P],
     "btvae_diag_gauss_loglik": [P, P, P, P, P, P, P, P, P, F, I, I, I, P],

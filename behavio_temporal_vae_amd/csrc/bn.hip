@@ -89,6 +89,45 @@ __global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const
     shift[c] = beta[c] - rm[c] * s;
 }
 
+// Train-mode BatchNorm folded into the Linear that consumes its output:  (Y*sc + sh) W^T + b = Y (W*sc)^T + (b + W sh)
+// with sc[k] = invstd[k] gamma[k], sh[k] = beta[k] - mean[k] sc[k].  One wave per output row n of W[N,K].
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_fold_linear_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ Wf, float* __restrict__ bf,
+                                                             float* __restrict__ scale, float* __restrict__ shift, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc = 0.f;
+    if (VEC == 4) {
+#pragma unroll 4
+        for (int k = lane * 4; k < K; k += 256) {
+            const float4 is = *reinterpret_cast<const float4*>(invstd + k), ga = *reinterpret_cast<const float4*>(gamma + k);
+            const float4 be = *reinterpret_cast<const float4*>(beta + k), mu = *reinterpret_cast<const float4*>(mean + k);
+            const float4 w = *reinterpret_cast<const float4*>(W + (size_t)n * K + k);
+            const float4 sc = make_float4(is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w);
+            const float4 sh = make_float4(be.x - mu.x * sc.x, be.y - mu.y * sc.y, be.z - mu.z * sc.z, be.w - mu.w * sc.w);
+            *reinterpret_cast<float4*>(Wf + (size_t)n * K + k) = make_float4(w.x * sc.x, w.y * sc.y, w.z * sc.z, w.w * sc.w);
+            acc = fmaf(w.x, sh.x, fmaf(w.y, sh.y, fmaf(w.z, sh.z, fmaf(w.w, sh.w, acc))));
+            if (n == 0) { *reinterpret_cast<float4*>(scale + k) = sc; *reinterpret_cast<float4*>(shift + k) = sh; }
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) {
+            const float sc = invstd[k] * gamma[k];
+            const float sh = beta[k] - mean[k] * sc;
+            const float w = W[(size_t)n * K + k];
+            Wf[(size_t)n * K + k] = w * sc;
+            acc = fmaf(w, sh, acc);
+            if (n == 0) { scale[k] = sc; shift[k] = sh; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) bf[n] = b[n] + acc;
+}
+
 // ---- forward apply: Out = (Y - mean) * invstd * gamma + beta (+ R) ----
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ Y, const float* __restrict__ mean,
@@ -417,6 +456,20 @@ BTVAE_API int btvae_bn_fold_eval(const float* gamma, const float* beta, const fl
     return check_launch("bn_fold_eval");
 }
 
+// Weights of a Linear[N,K] that takes the OUTPUT of a train-mode BatchNorm over K features, rewritten to take the
+// BatchNorm's INPUT Y instead:  Wf = W * sc (per input column), bf = b + W sh; also writes sc[K], sh[K].
+BTVAE_API int btvae_bn_fold_linear(const float* W, const float* b, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, float* Wf, float* bf, float* scale, float* shift, int N, int K, void* stream) {
+    BTVAE_REQUIRE(W && b && mean && invstd && gamma && beta && Wf && bf && scale && shift, "bn_fold_linear: null pointer");
+    BTVAE_REQUIRE(N > 0 && K > 0, "bn_fold_linear: bad shape N=%d K=%d", N, K);
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (K % 4 == 0 && al(W) && al(Wf) && al(mean) && al(invstd) && al(gamma) && al(beta) && al(scale) && al(shift))
+        hipLaunchKernelGGL((bn_fold_linear_kernel<4>), dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, b, mean, invstd, gamma, beta, Wf, bf, scale, shift, N, K);
+    else
+        hipLaunchKernelGGL((bn_fold_linear_kernel<1>), dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, b, mean, invstd, gamma, beta, Wf, bf, scale, shift, N, K);
+    return check_launch("bn_fold_linear");
+}
+
 BTVAE_API int btvae_bn_apply_fwd(const float* Y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                  const float* R, const unsigned char* keep, float keep_scale, float* Out, int M, int N,
                                  void* stream) {
@@ -432,11 +485,12 @@ BTVAE_API int btvae_bn_apply_fwd(const float* Y, const float* mean, const float*
 }
 
 // BatchNorm+ReLU backward.  G = dL/d(BN output), Y = post-ReLU pre-BN activations saved by the forward.
-// Writes dgamma, dbeta ((+)= when accumulate), dPre = dL/d(pre-ReLU linear output) and dbias = column sums of dPre.
+// Writes dgamma, dbeta ((+)= when accumulate), dPre = dL/d(pre-ReLU linear output) and dbias (+)= column sums of dPre;
+// dbias_cur (may be null) receives this call's column sums alone, whatever `accumulate` says.
 // `scratch` needs 3 * btvae_strip_chunks(M) * N floats.
 BTVAE_API int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mean, const float* invstd, const float* gamma,
                                 const unsigned char* keep, float keep_scale,
-                                float* dgamma, float* dbeta, float* dbias, float* dPre, float* scratch, int M, int N,
+                                float* dgamma, float* dbeta, float* dbias, float* dbias_cur, float* dPre, float* scratch, int M, int N,
                                 int accumulate, void* stream) {
     BTVAE_REQUIRE(G && Y && mean && invstd && gamma && dgamma && dbeta && dbias && dPre && scratch, "bn_relu_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -453,7 +507,7 @@ BTVAE_API int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mea
     colsum_finalize(s, p2, chunks, 2, N, dbeta, dgamma, cur_dbeta, cur_dgamma, accumulate);
     if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc, 1.f / (float)M);
     else    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc, 1.f / (float)M);
-    colsum_finalize(s, p1, chunks, 1, N, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
+    colsum_finalize(s, p1, chunks, 1, N, dbias, (float*)nullptr, dbias_cur, (float*)nullptr, accumulate);
     return check_launch("bn_relu_bwd");
 }
 
@@ -487,7 +541,7 @@ BTVAE_API int btvae_bn_relu_bwd_sums(const float* G, const float* Y, const float
 // Second half: dPre and dbias from the batch-wide sums (sums[0] = sum g, sums[1] = sum g*xhat over total_rows rows).
 BTVAE_API int btvae_bn_relu_bwd_apply(const float* G, const float* Y, const float* mean, const float* invstd, const float* gamma,
                                       const unsigned char* keep, float keep_scale, const float* sums, long long total_rows,
-                                      float* dbias, float* dPre, float* scratch, int M, int N, int accumulate, void* stream) {
+                                      float* dbias, float* dbias_cur, float* dPre, float* scratch, int M, int N, int accumulate, void* stream) {
     BTVAE_REQUIRE(G && Y && mean && invstd && gamma && sums && dbias && dPre && scratch, "bn_relu_bwd_apply: null pointer");
     BTVAE_REQUIRE(total_rows >= M, "bn_relu_bwd_apply: total_rows %lld < local rows %d", total_rows, M);
     hipStream_t s = (hipStream_t)stream;
@@ -498,14 +552,14 @@ BTVAE_API int btvae_bn_relu_bwd_apply(const float* G, const float* Y, const floa
         hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, rpc, inv);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, rpc, inv);
-    colsum_finalize(s, scratch, chunks, 1, N, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
+    colsum_finalize(s, scratch, chunks, 1, N, dbias, (float*)nullptr, dbias_cur, (float*)nullptr, accumulate);
     return check_launch("bn_relu_bwd_apply");
 }
 
 // Backward of Linear -> ReLU (-> Dropout) without BatchNorm: dPre = (Y > 0) * dropout(G), dbias (+)= column sums.
 // scratch: btvae_strip_chunks(M) * N floats.
 BTVAE_API int btvae_relu_bwd(const float* G, const float* Y, const unsigned char* keep, float keep_scale, float* dbias,
-                             float* dPre, float* scratch, int M, int N, int accumulate, void* stream) {
+                             float* dbias_cur, float* dPre, float* scratch, int M, int N, int accumulate, void* stream) {
     BTVAE_REQUIRE(G && Y && dbias && dPre && scratch, "relu_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
@@ -515,16 +569,17 @@ BTVAE_API int btvae_relu_bwd(const float* G, const float* Y, const unsigned char
         hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc, 1.f);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc, 1.f);
-    colsum_finalize(s, scratch, chunks, 1, N, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
+    colsum_finalize(s, scratch, chunks, 1, N, dbias, (float*)nullptr, dbias_cur, (float*)nullptr, accumulate);
     return check_launch("relu_bwd");
 }
 
 // Scratch floats btvae_bn_relu_bwd needs for an [M,N] activation.
 BTVAE_API long long btvae_bn_relu_bwd_scratch(int M, int N) { return (long long)3 * chunk_count(M) * N + 2LL * N; }
 
-// out[N] (+)= column sums of G[M,N]; scratch needs btvae_strip_chunks(M) * N floats.
-BTVAE_API int btvae_colsum(const float* G, float* out, float* scratch, int M, int N, int accumulate, void* stream) {
-    BTVAE_REQUIRE(G && out && scratch, "colsum: null pointer");
+// out[N] (+)= column sums of G[M,N], cur[N] = the sums alone (either may be null); scratch needs
+// btvae_strip_chunks(M) * N floats.
+BTVAE_API int btvae_colsum(const float* G, float* out, float* cur, float* scratch, int M, int N, int accumulate, void* stream) {
+    BTVAE_REQUIRE(G && (out || cur) && scratch, "colsum: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N);
@@ -532,6 +587,6 @@ BTVAE_API int btvae_colsum(const float* G, float* out, float* scratch, int M, in
         hipLaunchKernelGGL((colsum_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, scratch, M, N, rpc);
     else
         hipLaunchKernelGGL((colsum_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, scratch, M, N, rpc);
-    colsum_finalize(s, scratch, chunks, 1, N, out, (float*)nullptr, (float*)nullptr, (float*)nullptr, accumulate);
+    colsum_finalize(s, scratch, chunks, 1, N, out, (float*)nullptr, cur, (float*)nullptr, accumulate);
     return check_launch("colsum");
 }

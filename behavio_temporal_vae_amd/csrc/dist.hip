@@ -115,14 +115,13 @@ __global__ __launch_bounds__(256) void diag_loglik_kernel(const float* __restric
 // dictionary tables: Uhat = U / ||U[:,v]||, UU[p][v] = Uhat[d,v]*Uhat[e,v] for packed p = d(d+1)/2+e (e<=d),
 // diag[p] = m^2 on the diagonal entries.  Sigma_packed = sigma^2 @ UU^T + diag.
 // ---------------------------------------------------------------------------------------------
-__global__ void dict_norm_kernel(const float* __restrict__ U, float* __restrict__ Uhat, float* __restrict__ norms, int D, int V) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V) return;
-    float s = 0.f;
-    for (int d = 0; d < D; ++d) { const float u = U[(size_t)d * V + v]; s += u * u; }
-    const float n = sqrtf(s);
-    norms[v] = n;
-    for (int d = 0; d < D; ++d) Uhat[(size_t)d * V + v] = U[(size_t)d * V + v] / n;
+// one wave per dictionary column v: lane d holds U[d][v] (D <= 64)
+__global__ __launch_bounds__(64) void dict_norm_kernel(const float* __restrict__ U, float* __restrict__ Uhat, float* __restrict__ norms, int D, int V) {
+    const int v = blockIdx.x, d = threadIdx.x;
+    const float u = d < D ? U[(size_t)d * V + v] : 0.f;
+    const float n = sqrtf(wave_sum(u * u));
+    if (d == 0) norms[v] = n;
+    if (d < D) Uhat[(size_t)d * V + v] = u / n;
 }
 
 __global__ void dict_tables_kernel(const float* __restrict__ Uhat, float* __restrict__ UU, float* __restrict__ diag, int D, int V, float m2) {
@@ -278,8 +277,20 @@ __global__ __launch_bounds__(1024) void elbo_scalars_kernel(const float* __restr
                                                             int nkl, float beta, float* __restrict__ out) {
     __shared__ double red[2][16];
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < nlog; i += 1024) a += logp[i];
-    for (int i = threadIdx.x; i < nkl; i += 1024) b += klrow[i];
+    // 16-byte loads over the aligned bulk (independent partial sums keep several loads in flight), scalars for the rest
+    auto total = [](const float* __restrict__ v, int n) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        const int n4 = ((reinterpret_cast<uintptr_t>(v) & 15) == 0) ? n / 4 : 0;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < n4; i += 1024) {
+            const float4 q = reinterpret_cast<const float4*>(v)[i];
+            s0 += q.x; s1 += q.y; s2 += q.z; s3 += q.w;
+        }
+        for (int i = 4 * n4 + threadIdx.x; i < n; i += 1024) s0 += v[i];
+        return (s0 + s1) + (s2 + s3);
+    };
+    a = total(logp, nlog);
+    b = total(klrow, nkl);
     a = wave_sum_d(a); b = wave_sum_d(b);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
     __syncthreads();
@@ -404,7 +415,7 @@ BTVAE_API int btvae_dict_prepare(const float* U, float* Uhat, float* norms, floa
     BTVAE_REQUIRE(U && Uhat && norms && UU && diag, "dict_prepare: null pointer");
     BTVAE_REQUIRE(D > 0 && D <= 64 && V > 0, "dict_prepare: D=%d must be in 1..64", D);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(dict_norm_kernel, dim3((V + 63) / 64), dim3(64), 0, s, U, Uhat, norms, D, V);
+    hipLaunchKernelGGL(dict_norm_kernel, dim3(V), dim3(64), 0, s, U, Uhat, norms, D, V);
     const size_t n = (size_t)(D * (D + 1) / 2) * V;
     hipLaunchKernelGGL(dict_tables_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Uhat, UU, diag, D, V, marginal_std_lim * marginal_std_lim);
     return check_launch("dict_prepare");

@@ -271,6 +271,22 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
     }
 }
 
+// out[n][k] (+)= scale[k] * sum_z slabs[z][n][k] + shift[k] * rowv[n]   (out is [rows][K])
+__global__ void slab_reduce_affine_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t n, int nslab, size_t stride,
+                                          int accumulate, const float* __restrict__ scale, const float* __restrict__ shift,
+                                          const float* __restrict__ rowv, int K) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        float v = 0.f;
+        for (int z = 0; z < nslab; ++z) v += slabs[(size_t)z * stride + i];
+        const int k = (int)(i % (size_t)K);
+        const size_t r = i / (size_t)K;
+        v = fmaf(scale[k], v, shift[k] * rowv[r]);
+        out[i] = accumulate ? out[i] + v : v;
+    }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 std::atomic<int> g_precision{0};   // 0: fp32 MFMA, 1: bf16 operands, 2: fp32 operands as three bf16 pieces (Linear layers only)
@@ -375,16 +391,16 @@ BTVAE_API int btvae_linear_dgrad(const float* dY, const float* W, const float* R
 
 // C[M,N] (+)= A^T B with A stored [K][M] (lda) and B stored [K][N] (ldb); the reduction is split over
 // workgroups into slabs held in `ws` and summed by a second kernel.  accumulate != 0 adds to C.
-BTVAE_API int btvae_matmul_tn(const float* A, int lda, const float* B, int ldb, float* C, float* ws, long long ws_floats,
-                              int M, int N, int K, int accumulate, int prof_kind, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
+static int matmul_tn_impl(const float* A, int lda, const float* B, int ldb, float* C, float* ws, long long ws_floats,
+                          int M, int N, int K, int accumulate, int prof_kind, hipStream_t s,
+                          const float* scale, const float* shift, const float* rowv) {
     GemmArgs a{}; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.ldc = N; a.M = M; a.N = N; a.K = K;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const size_t out_elems = (size_t)M * N;
     int splits = pick_splits(tiles, K, ws ? (size_t)ws_floats : 0, out_elems);
     ProfScope ps(prof_kind, s, 2.0 * M * N * K, 4.0 * ((double)K * M + (double)K * N + (double)M * N));
     const bool reduced_ok = prof_kind == PK_GEMM_WGRAD;
-    if (splits == 1 && !accumulate) {
+    if (splits == 1 && !accumulate && !scale) {
         a.C = C;
         return launch<LAY_M, LAY_M, EPI_PLAIN>(a, 1, s, "matmul_tn", reduced_ok);
     }
@@ -394,14 +410,29 @@ BTVAE_API int btvae_matmul_tn(const float* A, int lda, const float* B, int ldb, 
     if (rc) return rc;
     const int nslab = (K + a.kchunk - 1) / a.kchunk;
     const int blocks = (int)std::min<size_t>((out_elems + 255) / 256, 2048);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, C, out_elems, nslab, out_elems, accumulate);
+    if (scale) hipLaunchKernelGGL(slab_reduce_affine_kernel, dim3(blocks), dim3(256), 0, s, ws, C, out_elems, nslab, out_elems, accumulate, scale, shift, rowv, N);
+    else       hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, C, out_elems, nslab, out_elems, accumulate);
     return check_launch("matmul_tn.reduce");
+}
+
+BTVAE_API int btvae_matmul_tn(const float* A, int lda, const float* B, int ldb, float* C, float* ws, long long ws_floats,
+                              int M, int N, int K, int accumulate, int prof_kind, void* stream) {
+    return matmul_tn_impl(A, lda, B, ldb, C, ws, ws_floats, M, N, K, accumulate, prof_kind, (hipStream_t)stream, nullptr, nullptr, nullptr);
 }
 
 // dW[N,K] (+)= dY[M,N]^T X[M,K].
 BTVAE_API int btvae_linear_wgrad(const float* dY, const float* X, int ldx, float* dW, float* ws, long long ws_floats,
                                  int M, int N, int K, int accumulate, void* stream) {
     return btvae_matmul_tn(dY, N, X, ldx, dW, ws, ws_floats, N, K, M, accumulate, PK_GEMM_WGRAD, stream);
+}
+
+// Weight gradient of a Linear whose input is X = Y * scale + shift (column-wise, never materialised):
+// dW[N,K] (+)= scale[k] * (dY^T Y)[n,k] + shift[k] * dbias_cur[n], where dbias_cur[n] = sum_m dY[m,n].
+BTVAE_API int btvae_linear_wgrad_affine(const float* dY, const float* Y, int ldy, const float* scale, const float* shift,
+                                        const float* dbias_cur, float* dW, float* ws, long long ws_floats,
+                                        int M, int N, int K, int accumulate, void* stream) {
+    BTVAE_REQUIRE(scale && shift && dbias_cur, "linear_wgrad_affine: null scale / shift / dbias_cur");
+    return matmul_tn_impl(dY, N, Y, ldy, dW, ws, ws_floats, N, K, M, accumulate, PK_GEMM_WGRAD, (hipStream_t)stream, scale, shift, dbias_cur);
 }
 
 // C[M,N] = A[M,K] B[N,K]^T + bias[N].

@@ -34,14 +34,35 @@ class Unit:
 
 
 @dataclass
+class Normed:
+    """Output of a train-mode BatchNorm kept as its input plus the normalisation: ``y * scale + shift`` column-wise,
+    never written out.  Linear consumers fold scale/shift into their weights (``btvae_bn_fold_linear``)."""
+    y: torch.Tensor
+    mean: torch.Tensor
+    invstd: torch.Tensor
+    gamma: torch.Tensor
+    beta: torch.Tensor
+
+    @property
+    def shape(self):
+        return self.y.shape
+
+    @property
+    def device(self):
+        return self.y.device
+
+
+@dataclass
 class Saved:
-    x_in: torch.Tensor
+    x_in: torch.Tensor                       # input of the unit's Linear, or the tensor a Normed input is built on
     y: Optional[torch.Tensor] = None
     mean: Optional[torch.Tensor] = None
     invstd: Optional[torch.Tensor] = None
     keep: Optional[torch.Tensor] = None      # uint8 dropout keep flags of the unit's output
     keep_scale: float = 1.0
     total_rows: int = 0                      # rows the BatchNorm statistics span (> local rows under cross-rank sync)
+    x_scale: Optional[torch.Tensor] = None   # Normed input: its column scale / shift (x = x_in * x_scale + x_shift)
+    x_shift: Optional[torch.Tensor] = None
 
 
 class NetPlan:
@@ -131,15 +152,33 @@ def _check_train_supported(u: Unit, train: bool):
         raise ValueError("dropout probability must be below 1")
 
 
-def unit_forward(u: Unit, x: torch.Tensor, train: bool, saved: Optional[List[Saved]]) -> torch.Tensor:
-    """One Linear->ReLU->BatchNorm(->+x) unit (src/submodels.py:15-21,30-33) or a bare Linear."""
+FOLD_BN_INTO_CONSUMER = True     # train mode: leave BatchNorm outputs that only feed plain Linears unmaterialised
+
+
+def _linear_operands(lin: torch.nn.Linear, x):
+    """(A, W, b, scale, shift) of ``lin`` applied to ``x``: a tensor as is, a Normed input through folded weights."""
+    if not isinstance(x, Normed):
+        return x, lin.weight, lin.bias, None, None
+    N, K = lin.weight.shape
+    dev = x.device
+    Wf, bf = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+    sc, sh = torch.empty(K, device=dev), torch.empty(K, device=dev)
+    nv.call("btvae_bn_fold_linear", P(lin.weight), P(lin.bias), P(x.mean), P(x.invstd), P(x.gamma), P(x.beta), P(Wf), P(bf), P(sc), P(sh), N, K)
+    return x.y, Wf, bf, sc, sh
+
+
+def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_normed: bool = False):
+    """One Linear->ReLU->BatchNorm(->+x) unit (src/submodels.py:15-21,30-33) or a bare Linear.  ``x`` may be a
+    ``Normed`` (train mode, non-residual units).  With ``keep_normed`` the caller promises that every consumer of
+    the result is a plain (non-residual) Linear, and a BatchNorm unit without dropout returns a ``Normed``."""
     M, K = x.shape
     N = u.lin.out_features
     dev = x.device
-    W, b = u.lin.weight, u.lin.bias
     assert u.act, "bare Linear units are head outputs; use head_forward"
     _check_train_supported(u, train)
-    out = torch.empty(M, N, device=dev)
+    if isinstance(x, Normed) and (u.residual or not train):
+        raise RuntimeError("a residual unit needs its input materialised")
+    x, W, b, x_sc, x_sh = _linear_operands(u.lin, x)
     if u.bn is not None and train:
         tiles = (M + 127) // 128
         y = torch.empty(M, N, device=dev)
@@ -162,10 +201,13 @@ def unit_forward(u: Unit, x: torch.Tensor, train: bool, saved: Optional[List[Sav
         keep, ks = None, 1.0
         if u.dropout_p > 0.0:
             keep, ks = DROPOUT.keep(M, N, u.dropout_p, dev), 1.0 / (1.0 - u.dropout_p)
+        if saved is not None:
+            saved.append(Saved(x, y, mean, invstd, keep, ks, total_rows, x_sc, x_sh))
+        if keep_normed and FOLD_BN_INTO_CONSUMER and keep is None and not u.residual:
+            return Normed(y, mean, invstd, u.bn.weight, u.bn.bias)
+        out = torch.empty(M, N, device=dev)
         nv.call("btvae_bn_apply_fwd", P(y), P(mean), P(invstd), P(u.bn.weight), P(u.bn.bias), P(x) if u.residual else None,
                 P(keep), ks, P(out), M, N)
-        if saved is not None:
-            saved.append(Saved(x, y, mean, invstd, keep, ks, total_rows))
     elif u.bn is None and train:
         # unit built without BatchNorm: y = relu(x W^T + b) is what the backward needs; dropout / residual on top
         y = torch.empty(M, N, device=dev)
@@ -174,12 +216,14 @@ def unit_forward(u: Unit, x: torch.Tensor, train: bool, saved: Optional[List[Sav
         if u.dropout_p > 0.0:
             keep, ks = DROPOUT.keep(M, N, u.dropout_p, dev), 1.0 / (1.0 - u.dropout_p)
         if keep is not None or u.residual:
+            out = torch.empty(M, N, device=dev)
             nv.call("btvae_bn_apply_fwd", P(y), None, None, None, None, P(x) if u.residual else None, P(keep), ks, P(out), M, N)
         else:
             out = y
         if saved is not None:
-            saved.append(Saved(x, y, None, None, keep, ks))
+            saved.append(Saved(x, y, None, None, keep, ks, 0, x_sc, x_sh))
     else:
+        out = torch.empty(M, N, device=dev)
         scale = shift = None
         if u.bn is not None:
             scale, shift = torch.empty(N, device=dev), torch.empty(N, device=dev)
@@ -188,46 +232,60 @@ def unit_forward(u: Unit, x: torch.Tensor, train: bool, saved: Optional[List[Sav
     return out
 
 
-def head_forward(u: Unit, x: torch.Tensor, act: int, lo: float, hi: float, want_dfac: bool, want_sq: bool):
+def head_forward(u: Unit, x, act: int, lo: float, hi: float, want_dfac: bool, want_sq: bool):
     """Head output Linear fused with its clamp / softplus / relu non-linearity
-    (src/submodels.py:102-104,156-157).  Returns (value, dfac or None, value^2 or None)."""
+    (src/submodels.py:102-104,156-157).  ``x`` may be a ``Normed``.
+    Returns (value, dfac or None, value^2 or None, (scale, shift) of a Normed input or (None, None))."""
     M, K = x.shape
     N = u.lin.out_features
-    val = torch.empty(M, N, device=x.device)
-    dfac = torch.empty(M, N, device=x.device) if want_dfac else None
-    sq = torch.empty(M, N, device=x.device) if want_sq else None
-    nv.call("btvae_linear_head_fwd", P(x), K, P(u.lin.weight), P(u.lin.bias), act, float(lo), float(hi), P(val), P(dfac), P(sq), M, K, N)
-    return val, dfac, sq
+    dev = x.device
+    a, W, b, x_sc, x_sh = _linear_operands(u.lin, x)
+    val = torch.empty(M, N, device=dev)
+    dfac = torch.empty(M, N, device=dev) if want_dfac else None
+    sq = torch.empty(M, N, device=dev) if want_sq else None
+    nv.call("btvae_linear_head_fwd", P(a), K, P(W), P(b), act, float(lo), float(hi), P(val), P(dfac), P(sq), M, K, N)
+    return val, dfac, sq, (x_sc, x_sh)
 
 
 @dataclass
 class NetTape:
     trunk: List[Saved] = field(default_factory=list)
     heads: Dict[str, List[Saved]] = field(default_factory=dict)
-    head_in: Dict[str, torch.Tensor] = field(default_factory=dict)   # input of each head's output Linear
+    head_in: Dict[str, torch.Tensor] = field(default_factory=dict)   # input of each head's output Linear (a Normed's y)
+    head_in_affine: Dict[str, tuple] = field(default_factory=dict)    # (scale, shift) of that input when it was a Normed
     dfac: Dict[str, torch.Tensor] = field(default_factory=dict)
 
 
 def net_forward(plan: NetPlan, x: torch.Tensor, train: bool, tape: Optional[NetTape], head_specs: Dict[str, tuple], want_sq=()):
     """Whole ParameterizerNN + output non-linearities.  head_specs[name] = (act, lo, hi).
     Returns {name: value}, {name: value^2} (for names in want_sq)."""
+    # a unit's result may stay a Normed when everything that reads it is a plain Linear: the next unit of its chain
+    # if that is not residual, the first unit of every head for the trunk's last unit, the head's output Linear
     h = x
-    for u in plan.trunk:
-        h = unit_forward(u, h, train, tape.trunk if tape is not None else None)
+    nt = len(plan.trunk)
+    for i, u in enumerate(plan.trunk):
+        if i + 1 < nt:
+            normed_ok = not plan.trunk[i + 1].residual
+        else:
+            normed_ok = all(not units[0].residual for units in plan.heads.values())
+        h = unit_forward(u, h, train, tape.trunk if tape is not None else None, keep_normed=train and normed_ok)
     out, sqs = {}, {}
     for name, units in plan.heads.items():
         t = h
         sv = [] if tape is not None else None
-        for u in units[:-1]:
-            t = unit_forward(u, t, train, sv)
+        hidden = units[:-1]
+        for i, u in enumerate(hidden):
+            normed_ok = i + 1 == len(hidden) or not hidden[i + 1].residual
+            t = unit_forward(u, t, train, sv, keep_normed=train and normed_ok)
         act, lo, hi = head_specs[name]
-        val, dfac, sq = head_forward(units[-1], t, act, lo, hi, tape is not None, name in want_sq)
+        val, dfac, sq, affine = head_forward(units[-1], t, act, lo, hi, tape is not None, name in want_sq)
         out[name] = val
         if sq is not None:
             sqs[name] = sq
         if tape is not None:
             tape.heads[name] = sv
-            tape.head_in[name] = t
+            tape.head_in[name] = t.y if isinstance(t, Normed) else t
+            tape.head_in_affine[name] = affine
             tape.dfac[name] = dfac
     return out, sqs
 
@@ -238,6 +296,18 @@ def _grad_view(p: torch.nn.Parameter) -> torch.Tensor:
     return p.grad
 
 
+def _wgrad(lin: torch.nn.Linear, dy: torch.Tensor, x: torch.Tensor, x_scale, x_shift, db_cur, accumulate: bool):
+    """lin.weight.grad (+)= dy^T x', x' = x (plain input) or x * x_scale + x_shift (the input was a Normed)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    ws = WS.get("wgrad", WGRAD_WS_FLOATS, dy.device)
+    if x_scale is None:
+        nv.call("btvae_linear_wgrad", P(dy), P(x), K, P(_grad_view(lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
+    else:
+        nv.call("btvae_linear_wgrad_affine", P(dy), P(x), K, P(x_scale), P(x_shift), P(db_cur), P(_grad_view(lin.weight)), P(ws), ws.numel(),
+                M, N, K, int(accumulate))
+
+
 def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.Tensor], need_dx: bool, accumulate: bool):
     """Backward of a ReLU+BN unit.  g = dL/d(out).  Returns dL/d(x_in) (+ add_to, + g for residual units)."""
     M, N = g.shape
@@ -245,8 +315,9 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
     dev = g.device
     scr = WS.get("bnbwd", nv.lib().btvae_bn_relu_bwd_scratch(M, N), dev)
     dpre = torch.empty(M, N, device=dev)
+    db_cur = torch.empty(N, device=dev) if sv.x_scale is not None else None    # this pass's bias gradient, for the affine wgrad
     if u.bn is None:
-        nv.call("btvae_relu_bwd", P(g), P(sv.y), P(sv.keep), float(sv.keep_scale), P(_grad_view(u.lin.bias)), P(dpre), P(scr), M, N, int(accumulate))
+        nv.call("btvae_relu_bwd", P(g), P(sv.y), P(sv.keep), float(sv.keep_scale), P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
     elif sv.total_rows > M:
         # statistics span ranks: local column sums -> sum over ranks -> dPre with the batch-wide sums
         sums = torch.empty(2, N, device=dev)
@@ -254,13 +325,12 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
                 P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)), P(sums), P(scr), M, N, int(accumulate))
         BN_SYNC.sum_(sums)
         nv.call("btvae_bn_relu_bwd_apply", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
-                P(sums), int(sv.total_rows), P(_grad_view(u.lin.bias)), P(dpre), P(scr), M, N, int(accumulate))
+                P(sums), int(sv.total_rows), P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
     else:
         nv.call("btvae_bn_relu_bwd", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
                 P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)),
-                P(_grad_view(u.lin.bias)), P(dpre), P(scr), M, N, int(accumulate))
-    ws = WS.get("wgrad", WGRAD_WS_FLOATS, dev)
-    nv.call("btvae_linear_wgrad", P(dpre), P(sv.x_in), K, P(_grad_view(u.lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
+                P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
+    _wgrad(u.lin, dpre, sv.x_in, sv.x_scale, sv.x_shift, db_cur, accumulate)
     if not need_dx:
         return None
     r = None
@@ -287,9 +357,10 @@ def net_backward(plan: NetPlan, tape: NetTape, draw: Dict[str, torch.Tensor], ne
         t_in = tape.head_in[name]
         K = t_in.shape[1]
         cs = WS.get("colsum", nv.lib().btvae_strip_chunks(M) * N, dev)
-        nv.call("btvae_colsum", P(d), P(_grad_view(last.lin.bias)), P(cs), M, N, int(accumulate))
-        ws = WS.get("wgrad", WGRAD_WS_FLOATS, dev)
-        nv.call("btvae_linear_wgrad", P(d), P(t_in), K, P(_grad_view(last.lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
+        x_sc, x_sh = tape.head_in_affine.get(name, (None, None))
+        db_cur = torch.empty(N, device=dev) if x_sc is not None else None
+        nv.call("btvae_colsum", P(d), P(_grad_view(last.lin.bias)), P(db_cur), P(cs), M, N, int(accumulate))
+        _wgrad(last.lin, d, t_in, x_sc, x_sh, db_cur, accumulate)
         g = torch.empty(M, K, device=dev)
         nv.call("btvae_linear_dgrad", P(d), P(last.lin.weight), None, P(g), K, M, N, K)
         svs = tape.heads[name]

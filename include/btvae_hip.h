@@ -96,8 +96,8 @@ int btvae_bn_apply_fwd(const float* Y, const float* mean, const float* invstd, c
  * dPre = dL/d(Linear output).  scratch: btvae_bn_relu_bwd_scratch(M,N) floats. */
 long long btvae_bn_relu_bwd_scratch(int M, int N);
 int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mean, const float* invstd, const float* gamma,
-                      const unsigned char* keep, float keep_scale, float* dgamma, float* dbeta, float* dbias, float* dPre, float* scratch, int M, int N,
-                      int accumulate, void* stream);
+                      const unsigned char* keep, float keep_scale, float* dgamma, float* dbeta, float* dbias, float* dbias_cur,
+                      float* dPre, float* scratch, int M, int N, int accumulate, void* stream);
 /* btvae_bn_relu_bwd in two halves with a sum-all-reduce of sums[2][N] between them (statistics spanning ranks):
  * _sums leaves this rank's (sum g, sum g*xhat) and adds them into dbeta / dgamma; _apply takes the batch-wide sums
  * and the global row count.  scratch as for btvae_bn_relu_bwd. */
@@ -106,13 +106,24 @@ int btvae_bn_relu_bwd_sums(const float* G, const float* Y, const float* mean, co
                            float* scratch, int M, int N, int accumulate, void* stream);
 int btvae_bn_relu_bwd_apply(const float* G, const float* Y, const float* mean, const float* invstd, const float* gamma,
                             const unsigned char* keep, float keep_scale, const float* sums, long long total_rows,
-                            float* dbias, float* dPre, float* scratch, int M, int N, int accumulate, void* stream);
+                            float* dbias, float* dbias_cur, float* dPre, float* scratch, int M, int N, int accumulate, void* stream);
 /* Backward of Linear -> ReLU (-> Dropout) units built without BatchNorm (batch_normalization: false,
  * src/submodels.py:15-25): dPre = (Y>0) * dropout(G), dbias (+)= column sums.  scratch: btvae_strip_chunks(M)*N. */
 int btvae_relu_bwd(const float* G, const float* Y, const unsigned char* keep, float keep_scale, float* dbias,
-                   float* dPre, float* scratch, int M, int N, int accumulate, void* stream);
-/* out[N] (+)= column sums of G[M,N]; scratch: btvae_strip_chunks(M)*N floats. */
-int btvae_colsum(const float* G, float* out, float* scratch, int M, int N, int accumulate, void* stream);
+                   float* dbias_cur, float* dPre, float* scratch, int M, int N, int accumulate, void* stream);
+/* out[N] (+)= column sums of G[M,N], cur[N] = the sums alone (either may be null); scratch: btvae_strip_chunks(M)*N floats.
+ * The backward entry points above take the same optional `dbias_cur`: this call's bias gradient regardless of
+ * `accumulate`, which btvae_linear_wgrad_affine needs. */
+int btvae_colsum(const float* G, float* out, float* cur, float* scratch, int M, int N, int accumulate, void* stream);
+/* A Linear[N,K] fed by a train-mode BatchNorm (src/submodels.py:15-21 followed by the next block's Linear, :30-34,
+ * :63-68) computes (Y*sc + sh) W^T + b = Y (W*sc)^T + (b + W sh): Wf, bf are those weights, sc/sh[K] the BatchNorm's
+ * column scale and shift.  The normalised activation is then never written; the weight gradient follows from Y by
+ * btvae_linear_wgrad_affine: dW (+)= sc[k] (dY^T Y)[n,k] + sh[k] dbias_cur[n]. */
+int btvae_bn_fold_linear(const float* W, const float* b, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, float* Wf, float* bf, float* scale, float* shift, int N, int K, void* stream);
+int btvae_linear_wgrad_affine(const float* dY, const float* Y, int ldy, const float* scale, const float* shift,
+                              const float* dbias_cur, float* dW, float* ws, long long ws_floats,
+                              int M, int N, int K, int accumulate, void* stream);
 
 /* ---- reparameterisation, KL, likelihoods ---- */
 /* z = mu + sigma*eps (src/submodels.py:108-109) written next to the broadcast condition as decoder input rows

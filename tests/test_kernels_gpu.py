@@ -114,6 +114,37 @@ def test_dgrad_wgrad(dev, gemm_mode, M, N, K):
     close(dW, 2 * (c[0].t() @ c[2]), 2e-6, 6e-6 * math.sqrt(M), "wgrad accumulate")
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 1000, 1000), (130, 48, 1000), (70, 9, 33)])
+def test_bn_fold_linear_and_affine_wgrad(dev, gemm_mode, M, N, K):
+    """A Linear fed by a train-mode BatchNorm, computed from the BatchNorm's input: folded weights for the forward
+    product, scale/shift correction for the weight gradient (accumulating and overwriting)."""
+    Y = torch.relu(rnd(M, K, seed=3)); W = rnd(N, K, seed=4) * 0.1; b = rnd(N, seed=5)
+    mean = Y.mean(0); inv = 1 / torch.sqrt(Y.var(0, unbiased=False) + 1e-5)
+    gam = 1 + 0.3 * rnd(K, seed=6); bet = 0.2 * rnd(K, seed=7)
+    dY = rnd(M, N, seed=8)
+    sc = inv * gam; sh = bet - mean * sc
+    X = Y * sc + sh
+    ref_out = X @ W.T + b
+    ref_dW = dY.T @ X
+    d = {k: v.float().to(dev) for k, v in dict(Y=Y, W=W, b=b, mean=mean, inv=inv, gam=gam, bet=bet, dY=dY).items()}
+    Wf, bf = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+    scd, shd = torch.empty(K, device=dev), torch.empty(K, device=dev)
+    nv.call("btvae_bn_fold_linear", P(d["W"]), P(d["b"]), P(d["mean"]), P(d["inv"]), P(d["gam"]), P(d["bet"]), P(Wf), P(bf), P(scd), P(shd), N, K)
+    close(scd, sc, 1e-5, 1e-6, "scale"); close(shd, sh, 1e-5, 1e-6, "shift")
+    out = torch.empty(M, N, device=dev)
+    nv.call("btvae_matmul_nt_bias", P(d["Y"]), K, P(Wf), K, P(bf), P(out), N, M, N, K)
+    close(out, ref_out, 1e-4, 2e-5 * math.sqrt(K), "folded forward")
+    ws = torch.empty(4 * 1024 * 1024, device=dev)
+    cs = torch.empty(nv.lib().btvae_strip_chunks(M) * N, device=dev)
+    dbc = torch.empty(N, device=dev)
+    nv.call("btvae_colsum", P(d["dY"]), None, P(dbc), P(cs), M, N, 0)
+    dW = torch.full((N, K), 0.5, device=dev)
+    nv.call("btvae_linear_wgrad_affine", P(d["dY"]), P(d["Y"]), K, P(scd), P(shd), P(dbc), P(dW), P(ws), ws.numel(), M, N, K, 1)
+    close(dW, 0.5 + ref_dW, 1e-4, 2e-5 * math.sqrt(M), "affine wgrad (accumulate)")
+    nv.call("btvae_linear_wgrad_affine", P(d["dY"]), P(d["Y"]), K, P(scd), P(shd), P(dbc), P(dW), P(ws), ws.numel(), M, N, K, 0)
+    close(dW, ref_dW, 1e-4, 2e-5 * math.sqrt(M), "affine wgrad")
+
+
 def test_matmul_bias_and_mul(dev):
     M, K, N = 260, 100, 1176
     A, B, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
@@ -152,17 +183,21 @@ def test_batchnorm_fwd_bwd(dev, M, N):
     nscr = nv.lib().btvae_bn_relu_bwd_scratch(M, N)
     scr = torch.empty(nscr, device=dev)
     dgam, dbet, dbias = (torch.zeros(N, device=dev) for _ in range(3))
+    dbcur = torch.empty(N, device=dev)
     dpre = torch.empty(M, N, device=dev)
-    nv.call("btvae_bn_relu_bwd", P(d["G"]), P(d["Y"]), P(mean_d), P(inv_d), P(d["gam"]), None, 1.0, P(dgam), P(dbet), P(dbias), P(dpre), P(scr), M, N, 0)
+    nv.call("btvae_bn_relu_bwd", P(d["G"]), P(d["Y"]), P(mean_d), P(inv_d), P(d["gam"]), None, 1.0, P(dgam), P(dbet), P(dbias), P(dbcur), P(dpre), P(scr), M, N, 0)
     s = math.sqrt(M)
     close(dpre, pre.grad, 1e-4, 2e-6, "dpre")
     close(dgam, g64.grad, 1e-5, 3e-6 * s, "dgamma")
     close(dbet, b64.grad, 1e-5, 3e-6 * s, "dbeta")
     close(dbias, pre.grad.sum(0), 1e-5, 3e-6 * s, "dbias")
+    assert torch.equal(dbcur, dbias)          # not accumulating: the current sums are the gradient
     cs = torch.empty(nv.lib().btvae_strip_chunks(M) * N, device=dev)
     outc = torch.ones(N, device=dev)
-    nv.call("btvae_colsum", P(d["G"]), P(outc), P(cs), M, N, 1)
+    curc = torch.empty(N, device=dev)
+    nv.call("btvae_colsum", P(d["G"]), P(outc), P(curc), P(cs), M, N, 1)
     close(outc, 1 + G.double().sum(0), 1e-5, 3e-6 * s, "colsum")
+    close(curc, G.double().sum(0), 1e-5, 3e-6 * s, "colsum current")
 
 
 @pytest.mark.parametrize("threeD", [False, True])
