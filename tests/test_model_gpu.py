@@ -227,15 +227,18 @@ def test_config0_shape_train_steps(dev):
         assert np.median(d) < 3e-4 and d.max() < 7e-3, (k, np.median(d), d.max())
 
 
-def test_train_core_against_oracle_random_shapes(dev):
-    """Odd sizes (rows not multiples of the 128 tile, widths not multiples of 4) against the fp32 CPU oracle."""
+@pytest.mark.parametrize("hidden", [0, 1, 2])
+def test_train_core_against_oracle_random_shapes(dev, hidden):
+    """Odd sizes (rows not multiples of the 128 tile, widths not multiples of 4) against the fp32 CPU oracle, for
+    0, 1 and 2 residual middle layers: with none, every BatchNorm output but the heads' feeds a plain Linear and
+    stays unmaterialised."""
     from oracle import refimpl as R
     from behavio_temporal_vae_amd.vae_models import CVAE
     cfg = {"latent_dim": 7, "distribution_dict": {
         "posterior": {"dist_type": "normal", "sigma_lim": 0.05, "mu_upper_lim": 5.0, "mu_lower_lim": -5.0, "num_neurons": 70,
-                      "num_hidden_layers": 1, "dropout": False, "batch_normalization": True},
+                      "num_hidden_layers": hidden, "dropout": False, "batch_normalization": True},
         "likelihood": {"dist_type": "dict-gauss", "vocab_size": 13, "sigma_lim": 1e-4, "marginal_std_lim": 0.1, "mu_lower_lim": -3,
-                       "num_neurons": 70, "num_hidden_layers": 1, "dropout": False, "batch_normalization": True}}}
+                       "num_neurons": 70, "num_hidden_layers": hidden, "dropout": False, "batch_normalization": True}}}
     D, C, B, S = 10, 3, 150, 3
     torch.manual_seed(5)
     m = CVAE(input_dim=D, conditioner=Cdim(C), **cfg)
@@ -254,6 +257,33 @@ def test_train_core_against_oracle_random_shapes(dev):
         loss = m._train_step(x.to(dev), c.to(dev), opt, eps=eps.to(dev))
         got = [loss[k].item() for k in ("loss", "elbo", "rll", "kl")]
         assert rel_err(got, [ref[k] for k in ("loss", "elbo", "rll", "kl")]) < 1e-4, (t, got, ref)
+
+
+def test_unmaterialised_batchnorm_outputs_change_nothing(dev):
+    """Folding a BatchNorm into the Linear that reads it is a re-association only: the loss terms of two optimiser
+    steps and every gradient of the second agree with the materialising path to fp32 round-off (parameters are not
+    compared: Adam's first update is sign-like, so a weight whose gradient is round-off-sized may move either way)."""
+    from behavio_temporal_vae_amd import engine as E
+    from behavio_temporal_vae_amd.vae_models import CVAE
+    g = load_golden("tiny_dict_2d")
+    res = {}
+    for fold in (True, False):
+        E.FOLD_BN_INTO_CONSUMER = fold
+        try:
+            m = build(g, dev).train()
+            m.train_kwargs = {"num_mc_samples": int(g["S"]), "beta": 0.7, "gradient_clipping": True, "gradient_clipping_kwargs": {"max_norm": 1.0}}
+            opt = m.get_optimizer(lr=1e-3, weight_decay=1e-5)
+            losses = []
+            for t in range(2):
+                l = m._train_step(T(g["steps_x"][t]).to(dev), T(g["steps_c"][t]).to(dev), opt, eps=T(g["steps_eps"][t]).to(dev))
+                losses.append([l[k].item() for k in ("loss", "elbo", "rll", "kl")])
+            grads = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}
+            res[fold] = (np.array(losses), grads)
+        finally:
+            E.FOLD_BN_INTO_CONSUMER = True
+    assert rel_err(res[True][0], res[False][0]) < 1e-5
+    for n, gr in res[False][1].items():
+        assert (res[True][1][n] - gr).abs().max() <= 1e-4 * (gr.abs().max() + 1e-8), n
 
 
 def test_wide_conditioning_3d_fp32_and_bf16(dev):
