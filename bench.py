@@ -43,7 +43,7 @@ BREAKDOWN_STEPS = 3             # untimed steps with every launch event-timed, f
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X bf16 dense matrix peak (v_mfma_f32_32x32x16_bf16, 1024 FLOP/clk/SIMD)
 SPLIT_TERMS = 6                  # bf16 MFMAs issued per fp32 product in the split mode
 # HBM-side bytes of one launch of the dominant kernel (M=65536, N=K=1000) from PMC passes kept under profiles/
-DOMINANT_KERNEL_HBM_BYTES = {"fp32": 2 * 324658 * 1024 + 304764 * 1024, "fp32_split": 2 * 367599 * 1024 + 331523 * 1024}
+DOMINANT_KERNEL_HBM_BYTES = {"fp32": 2 * 324658 * 1024 + 304764 * 1024, "fp32_split": 2 * 366460 * 1024 + 260010 * 1024}
 
 
 KERNEL_NAME = {"fp32_split": "gemm_split_mfma", "fp32": "gemm_f32_mfma", "bf16": "gemm_bf16_mfma"}
