@@ -25,7 +25,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# effective config0 (reference: config_files/config0.json; batch 4096 per BASELINE.json configs[1])
+# effective config0 (reference: config_files/config0.json) at the benchmark's batch of 4096 per GPU
 CONFIG0_MODEL = {
     "latent_dim": 48,
     "distribution_dict": {
