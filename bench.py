@@ -111,6 +111,29 @@ GIPUZKOA_MODEL = {
                        "dropout": True, "dropout_rate": 0.2, "batch_normalization": True, "resnet": False}}}
 
 
+def cpu_scoring_baseline(K=1000, N=32):
+    """The CPU oracle's K-sample importance-weighted scoring on the host cores (gipuzkoa-shaped model, eval mode):
+    one warm-up call on N/4 profiles, then one timed call on N."""
+    from oracle import refimpl as R
+    cores = os.cpu_count() or 1
+    threads = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    torch.set_num_threads(threads)
+    spec = R.model_spec(24, C, GIPUZKOA_MODEL)
+    sd = R.init_state(spec, SEED)
+    g = torch.Generator().manual_seed(SEED)
+    x = torch.randn(N, 24, generator=g).clamp(-3, 5)
+    ang = torch.rand(N, 2, generator=g) * (2 * math.pi)
+    c = torch.cat([torch.cos(ang), torch.sin(ang)], 1)
+    with torch.no_grad():
+        R.iw_loglikelihood(sd, spec, x[:N // 4], c[:N // 4], torch.randn(K, N // 4, spec.latent_dim, generator=g))
+        eps = torch.randn(K, N, spec.latent_dim, generator=g)
+        t0 = time.perf_counter()
+        R.iw_loglikelihood(sd, spec, x, c, eps)
+        dt = time.perf_counter() - t0
+    return {"value": N / dt, "unit": "profiles/s", "cores": threads, "kind": "port",
+            "sample": f"{N} profiles at K={K} in one call after a warm-up call on {N // 4}, {dt:.2f} s"}
+
+
 def scoring_benchmark(dev, rank, world, n_profiles, K, chunk):
     """K-sample importance-weighted log-likelihood of the config0_gipuzkoa-shaped model (D=24, L=24, C=4, H=1000,
     V=100, eval mode): every rank scores its own ``n_profiles`` resident profiles (weak scaling), one reduce of
@@ -318,6 +341,8 @@ def main():
             out["bf16_option"] = bf16_opt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            if scoring is not None:
+                scoring["cpu_baseline"] = cpu_scoring_baseline(args.scoring_k)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
