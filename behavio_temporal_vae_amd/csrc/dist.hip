@@ -270,6 +270,70 @@ __global__ __launch_bounds__(256) void mvn_rows_kernel(const float* __restrict__
     }
 }
 
+
+// Forward-only variant for D <= 32: two rows per wave (lanes 0..31 and 32..63 each hold one covariance), same
+// elimination; a 24-wide problem otherwise leaves 40 of 64 lanes idle.
+template <int DP>
+__global__ __launch_bounds__(256) void mvn_rows_pair_kernel(const float* __restrict__ Sp, const float* __restrict__ mu,
+                                                            const float* __restrict__ x, float* __restrict__ logp,
+                                                            int rows, int B, int D) {
+    static_assert(DP % 4 == 0 && DP <= 32, "padded dimension must be a multiple of 4, at most 32");
+    constexpr int NPMAX = DP * (DP + 1) / 2;
+    __shared__ float sh[8][NPMAX];
+    __shared__ __attribute__((aligned(16))) float line[8][2 * DP + 4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 31, half = lane >> 5, slot = w * 2 + half;
+    const int row_raw = blockIdx.x * 8 + slot;
+    const bool live = row_raw < rows;
+    const int row = live ? row_raw : rows - 1;
+    const int NP = D * (D + 1) / 2;
+    float* cw = line[slot];
+
+    for (int p = i; p < NP; p += 32) sh[slot][p] = Sp[(size_t)row * NP + p];
+    __builtin_amdgcn_wave_barrier();
+
+    float a[DP];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+        float v = (i == j) ? 1.f : 0.f;
+        if (i < D && j < D) { const int mx = max(i, j), mn = min(i, j); v = sh[slot][mx * (mx + 1) / 2 + mn]; }
+        if (i >= DP) v = 0.f;
+        a[j] = v;
+    }
+    float r = 0.f;
+    if (i < D) r = x[(size_t)(row % B) * D + i] - mu[(size_t)row * D + i];
+
+    float logdet = 0.f, maha = 0.f;
+#pragma unroll 1
+    for (int k = 0; k < DP; ++k) {
+        const float c = a[0];
+        float sv[DP];
+        {   // publish the pivot column of this half, read it back as the pivot row (see mvn_rows_kernel)
+            const int m = (4 - (k & 3)) & 3;
+            if (i < DP) { cw[i + m] = c; cw[i + m + DP] = c; }
+            __builtin_amdgcn_wave_barrier();
+            const float* src = cw + (k + m);
+#pragma unroll
+            for (int j = 0; j < DP; j += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(src + j);
+                sv[j] = t.x; sv[j + 1] = t.y; sv[j + 2] = t.z; sv[j + 3] = t.w;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        const float piv = sv[0];
+        logdet += logf(piv);
+        const float rp = 1.f / piv;
+        const float yk = __shfl(r, (lane & 32) | k, 64);
+        maha = fmaf(yk * yk, rp, maha);
+        const float f = (i > k) ? c * rp : 0.f;
+        r = fmaf(-f, yk, r);
+#pragma unroll
+        for (int j = 1; j < DP; ++j) a[j - 1] = fmaf(-f, sv[j], a[j]);
+        a[DP - 1] = c;
+    }
+    if (live && i == 0) logp[row] = -0.5f * ((float)D * LOG_2PI + maha) - 0.5f * logdet;
+}
+
 // ---------------------------------------------------------------------------------------------
 // ELBO scalars: out = [loss, elbo, rll, kl], rll = mean(logp), kl = mean(klrow), loss = -(rll - beta*kl)
 // ---------------------------------------------------------------------------------------------
@@ -359,6 +423,16 @@ template <bool BWD>
 int launch_mvn(int D, const float* Sp, const float* mu, const float* x, const float* dfac_mu, const float* g_rows, float g_const,
                float* logp, float* dmu_raw, float* Pg, int rows, int B, hipStream_t s) {
     dim3 grid((rows + 3) / 4), block(256);
+    if (!BWD && D <= 32) {
+        dim3 pgrid((rows + 7) / 8);
+#define BTVAE_MVN_PAIR(DPV) hipLaunchKernelGGL((mvn_rows_pair_kernel<DPV>), pgrid, block, 0, s, Sp, mu, x, logp, rows, B, D)
+        if (D <= 8) BTVAE_MVN_PAIR(8);
+        else if (D <= 16) BTVAE_MVN_PAIR(16);
+        else if (D <= 24) BTVAE_MVN_PAIR(24);
+        else BTVAE_MVN_PAIR(32);
+#undef BTVAE_MVN_PAIR
+        return btvae::check_launch("mvn_rows");
+    }
 #define BTVAE_MVN_CASE(DPV) hipLaunchKernelGGL((mvn_rows_kernel<DPV, BWD>), grid, block, 0, s, Sp, mu, x, dfac_mu, g_rows, g_const, logp, dmu_raw, Pg, rows, B, D)
     if (D <= 8) BTVAE_MVN_CASE(8);
     else if (D <= 16) BTVAE_MVN_CASE(16);
