@@ -14,6 +14,7 @@
 #include "gemm_common.h"
 #include "gemm_bf16.h"
 #include "gemm_split.h"
+#include "gemm_head64.h"
 #include <algorithm>
 #include <atomic>
 
@@ -378,6 +379,17 @@ BTVAE_API int btvae_linear_head_fwd(const float* X, int ldx, const float* W, con
     GemmArgs a{}; a.A = X; a.lda = ldx; a.B = W; a.ldb = K; a.C = Out; a.ldc = N; a.M = M; a.N = N; a.K = K;
     a.bias = b; a.C2 = Dfac; a.C3 = Sq; a.act = act; a.lo = lo; a.hi = hi;
     ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    // narrow heads (N <= 64) in the split mode: 128x64 tile instead of a mostly padded 128x128 one
+    const bool vec_in = (ldx % 4 == 0) && (K % 4 == 0) && aligned16(X) && aligned16(W);
+    if (g_precision.load(std::memory_order_relaxed) == 2 && N <= NBN && vec_in && M > 0 && K > 0) {
+        BTVAE_REQUIRE(X && W && Out, "linear_head_fwd: null operand");
+        BTVAE_REQUIRE(ldx >= K, "linear_head_fwd: ldx %d < K %d", ldx, K);
+        a.a_vec = a.b_vec = 1;
+        a.c_vec = (N % 4 == 0) && aligned16(Out) && (!Dfac || aligned16(Dfac)) && (!Sq || aligned16(Sq));
+        a.tiles_m = (M + BM - 1) / BM; a.tiles_n = 1; a.kchunk = K;
+        hipLaunchKernelGGL(gemm_split_head64, dim3((unsigned)a.tiles_m), dim3(256), 0, (hipStream_t)stream, a);
+        return check_launch("linear_head_fwd");
+    }
     return launch<LAY_K, LAY_K, EPI_HEAD>(a, 1, (hipStream_t)stream, "linear_head_fwd", true);
 }
 

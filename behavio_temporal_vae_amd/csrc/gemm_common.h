@@ -33,6 +33,22 @@ struct GemmArgs {
 
 __device__ __forceinline__ float softplus5(float x) { return x > 5.f ? x : log1pf(expf(x)); }
 
+// head non-linearity of one raw output: value and d value / d raw  (act 0: clamp, 1: clamp(softplus), 2: clamp(relu))
+__device__ __forceinline__ void head_value(const GemmArgs& p, float raw, float& val, float& df) {
+    if (p.act == 0) {
+        val = fminf(fmaxf(raw, p.lo), p.hi);
+        df = (raw >= p.lo && raw <= p.hi) ? 1.f : 0.f;
+    } else if (p.act == 1) {
+        const float sp = softplus5(raw);
+        val = fminf(fmaxf(sp, p.lo), p.hi);
+        df = (sp >= p.lo && sp <= p.hi) ? (raw > 5.f ? 1.f : 1.f / (1.f + expf(-raw))) : 0.f;
+    } else {
+        const float rl = fmaxf(raw, 0.f);
+        val = fminf(fmaxf(rl, p.lo), p.hi);
+        df = (raw > 0.f && rl >= p.lo && rl <= p.hi) ? 1.f : 0.f;
+    }
+}
+
 // `red` is LDS scratch of at least 6*128 floats that no wave still reads as a tile.
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x16 (&acc)[2][2], float* red, int m0, int n0, int tile_m) {

@@ -65,8 +65,9 @@ def test_linear_relu_stats(dev, gemm_mode, M, K, N):
     close(rv, 0.9 + 0.1 * yr.var(0, unbiased=True), 2e-5, 0, "running_var")
 
 
-def test_linear_relu_affine_and_head(dev, gemm_mode):
-    M, K, N = 200, 96, 100
+@pytest.mark.parametrize("M,K,N", [(200, 96, 100), (300, 1000, 48), (130, 52, 24), (257, 40, 10), (64, 1000, 64)])
+def test_linear_relu_affine_and_head(dev, gemm_mode, M, K, N):
+    """N <= 64 takes the narrow head kernel in the split mode (N=10: its scalar-store path), N=100 the 128-wide tile."""
     X, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.3), rnd(N, seed=3)
     sc, sh, R = rnd(N, seed=4), rnd(N, seed=5), rnd(M, N, seed=6)
     d = [t.float().to(dev) for t in (X, W, b, sc, sh, R)]
@@ -74,7 +75,7 @@ def test_linear_relu_affine_and_head(dev, gemm_mode):
     nv.call("btvae_linear_relu_affine_fwd", P(d[0]), K, P(d[1]), P(d[2]), P(d[3]), P(d[4]), P(d[5]), P(out), M, K, N)
     c = [t.cpu().double() for t in d]
     ref = torch.relu(c[0] @ c[1].t() + c[2]) * c[3] + c[4] + c[5]
-    close(out, ref, 1e-5, 2e-5, "affine")
+    close(out, ref, 1e-5, 2e-6 * math.sqrt(K) + 2e-5, "affine")
     raw = c[0] @ c[1].t() + c[2]
     for act, lo, hi in ((0, -0.5, 0.8), (1, 0.05, 1.0), (2, 1e-4, 0.62)):
         o, df, sq = (torch.empty(M, N, device=dev) for _ in range(3))
@@ -87,8 +88,8 @@ def test_linear_relu_affine_and_head(dev, gemm_mode):
         else:
             val = torch.relu(rr).clamp(lo, hi)
         val.sum().backward()
-        close(o, val, 1e-5, 2e-5, f"head{act}")
-        close(sq, val ** 2, 1e-5, 2e-5, f"head{act}.sq")
+        close(o, val, 1e-5, 2e-6 * math.sqrt(K) + 2e-5, f"head{act}")
+        close(sq, val ** 2, 1e-5, 4e-6 * math.sqrt(K) + 2e-5, f"head{act}.sq")
         # the derivative factor may differ where raw sits within round-off of a clamp edge
         edge = ((raw - lo).abs() < 1e-4) | ((raw - hi).abs() < 1e-4) | (raw.abs() < 1e-4)
         if act == 1:
