@@ -8,23 +8,30 @@
 // 128x128x16 block tile, 4 waves (2x2) of 64x64, register staging several k-tiles deep (global latency is longer than
 // one tile's 24 MFMAs), double-buffered LDS, one barrier per k-tile.
 // Operands stay fp32 in HBM; each thread splits the 16 values it stages per tile into the three bf16 planes of its
-// operand and stores them k-contiguously: an LDS plane is [128 rows][16 k] bf16 with 32-byte rows, swizzled instead
-// of padded (s_off), one 16-byte read per plane and MFMA operand: 48 KiB per workgroup.
-// m/n-contiguous operands are transposed in registers (2k x 4m patch per thread).
+// operand.  k-contiguous operands: an LDS plane is [128 rows][16 k] bf16 with 32-byte rows, swizzled instead of padded
+// (s_off), one 16-byte read per plane and MFMA operand.  m/n-contiguous operands keep their orientation: a plane is
+// [16 k][128 m] bf16 (320-byte row pitch), stored with 8-byte writes straight from the loaded rows, and the MFMA operand
+// is gathered by the transposing LDS read (ds_read_b64_tr_b16, two per plane and operand).  48-60 KiB per workgroup.
 #pragma once
 #include "gemm_common.h"
 
 namespace btvae_gemm {
 
 constexpr int SBK = 16;                  // k elements per tile = one bf16 MFMA step
-constexpr int SPLANE = 128 * SBK;        // bf16 elements per plane (4 KiB)
+constexpr int SPLANE = 128 * SBK;        // bf16 elements per plane of a k-contiguous operand (4 KiB)
+constexpr int MPITCH = 160;              // m-contiguous operand: bf16 elements between k rows (128 + 32 of padding: the
+                                         // 4 rows x 2 column halves a 32-lane half gathers land on 64 distinct banks)
+constexpr int MPLANE = SBK * MPITCH;     // bf16 elements per plane of an m-contiguous operand (5 KiB)
+template <int LAY> constexpr int plane_elems() { return LAY == 0 ? SPLANE : MPLANE; }
 
 typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
+typedef short ss16x4 __attribute__((ext_vector_type(4)));
+typedef short ss16x8 __attribute__((ext_vector_type(8)));
 
 // Element offset of (row, 8-k half c) inside a plane.  Rows are permuted inside groups of four (low two bits XORed
 // with the next two) and the two 16-byte halves swap on every second group of eight: with that, the 16-byte fragment
-// reads, the 8-byte stores of k-contiguous operands and the 4-byte stores of transposed operands are all free of
-// bank conflicts (checked by enumeration against the per-instruction lane groups and bank widths).
+// reads and the 8-byte stores of k-contiguous operands are free of bank conflicts (checked by enumeration against the
+// per-instruction lane groups and bank widths).
 __device__ __forceinline__ int s_off(int row, int c) {
     const int pr = (row & ~3) | ((row ^ (row >> 2)) & 3);
     return pr * SBK + ((c ^ ((pr >> 3) & 1)) << 3);
@@ -47,8 +54,8 @@ __device__ __forceinline__ void sput4(SStage& st, int slot, const float4 a) {
     st.v[4 * slot] = a.x; st.v[4 * slot + 1] = a.y; st.v[4 * slot + 2] = a.z; st.v[4 * slot + 3] = a.w;
 }
 
-// LAY_K: thread f (two passes) owns row f>>2, k = 4*(f&3) .. +3.  LAY_M: thread owns k = 2*(tid&7), +1 and
-// m = 4*(tid>>3) .. +3.
+// LAY_K: thread f (two passes) owns row f>>2, k = 4*(f&3) .. +3.  LAY_M: thread owns k = 2*(tid>>5), +1 and
+// m = 4*(tid&31) .. +3.
 template <int LAY, bool FULL>
 __device__ __forceinline__ void s_g2r(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int kend,
                                       int tid, SStage& st) {
@@ -64,7 +71,7 @@ __device__ __forceinline__ void s_g2r(const float* __restrict__ P, int ld, int r
             sput4(st, q, a);
         }
     } else {
-        const int kp = tid & 7, mq = tid >> 3;
+        const int mq = tid & 31, kp = tid >> 5;          // a wave's 32-lane half reads 512 contiguous bytes of a k row
         const int gm = row0 + (mq << 2);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -95,18 +102,39 @@ __device__ __forceinline__ void s_r2s(__bf16* S, int tid, const SStage& st) {
             *reinterpret_cast<uint2*>(dst + 2 * SPLANE) = make_uint2(L0, L1);
         }
     } else {
-        const int kp = tid & 7, mq = tid >> 3;
+        const int mq = tid & 31, kp = tid >> 5;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (mq << 2) + i;
-            unsigned H, M, L;
-            split2(v[i], v[4 + i], H, M, L);                      // k = 2kp (low half), 2kp + 1 (high half)
-            __bf16* dst = S + s_off(row, kp >> 2) + ((kp & 3) << 1);
-            *reinterpret_cast<unsigned*>(dst) = H;
-            *reinterpret_cast<unsigned*>(dst + SPLANE) = M;
-            *reinterpret_cast<unsigned*>(dst + 2 * SPLANE) = L;
+        for (int j = 0; j < 2; ++j) {
+            unsigned H0, M0, L0, H1, M1, L1;
+            split2(v[4 * j], v[4 * j + 1], H0, M0, L0);           // m = 4mq, 4mq + 1 of k row 2kp + j
+            split2(v[4 * j + 2], v[4 * j + 3], H1, M1, L1);       // m = 4mq + 2, 4mq + 3
+            __bf16* dst = S + (kp * 2 + j) * MPITCH + (mq << 2);
+            *reinterpret_cast<uint2*>(dst) = make_uint2(H0, H1);
+            *reinterpret_cast<uint2*>(dst + MPLANE) = make_uint2(M0, M1);
+            *reinterpret_cast<uint2*>(dst + 2 * MPLANE) = make_uint2(L0, L1);
         }
     }
+}
+
+// MFMA operand (row = lane & 31 of the 32-row block at `blk`, k = 8*(lane>>5) .. +7) of one plane.
+// k-contiguous plane: one 16-byte read at the lane's swizzled offset `off` = s_off(blk + (lane&31), lane>>5).
+// m-contiguous plane: two transposing reads; `off` = (8*(lane>>5) + q) * MPITCH + blk + 16*((lane>>4)&1) + 4p with
+// q = (lane&15)>>2, p = lane&3 (each 16-lane group gathers a 4-k x 16-m block; a lane receives its m's four k).
+// Every lane of the wave must be active at the transposing reads.
+template <int LAY>
+__device__ __forceinline__ sbf16x8 s_frag(const __bf16* plane, int off) {
+    if (LAY == LAY_K) return *reinterpret_cast<const sbf16x8*>(plane + off);
+    typedef __attribute__((address_space(3))) ss16x4 lds_s16x4;
+    const ss16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plane + off));
+    const ss16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plane + off + 4 * MPITCH));
+    const ss16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(sbf16x8, v);
+}
+
+template <int LAY>
+__device__ __forceinline__ int s_frag_off(int blk, int lane) {
+    if (LAY == LAY_K) return s_off(blk + (lane & 31), lane >> 5);
+    return (8 * (lane >> 5) + ((lane & 15) >> 2)) * MPITCH + blk + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 }
 
 #ifndef BTVAE_SPLIT_PD
@@ -122,10 +150,10 @@ __device__ __forceinline__ void s_r2s(__bf16* S, int tid, const SStage& st) {
 template <int AL, int BL, int EPI>
 __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const GemmArgs p) {
     constexpr int PD = BTVAE_SPLIT_PD;
-    __shared__ __attribute__((aligned(16))) __bf16 smem[2][2][3 * SPLANE];
+    constexpr int PLA = plane_elems<AL>(), PLB = plane_elems<BL>();
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2][3 * PLA + 3 * PLB];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
-    const int li = lane & 31, lh = lane >> 5;
 
     int bid = blockIdx.x;
     {
@@ -164,8 +192,8 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
     SStage sa[PD], sb[PD];
     if (nk > 0) {
         fetch(0, sa[0], sb[0]);
-        s_r2s<AL>(smem[0][0], tid, sa[0]);
-        s_r2s<BL>(smem[0][1], tid, sb[0]);
+        s_r2s<AL>(smem[0], tid, sa[0]);
+        s_r2s<BL>(smem[0] + 3 * PLA, tid, sb[0]);
     }
 #pragma unroll
     for (int j = 1; j <= PD; ++j) fetch(j, sa[j % PD], sb[j % PD]);
@@ -174,7 +202,7 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
     // fragment offsets of this lane (same in every plane and buffer)
     int oa[2], ob[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { oa[i] = s_off(wr * 64 + i * 32 + li, lh); ob[i] = s_off(wc * 64 + i * 32 + li, lh); }
+    for (int i = 0; i < 2; ++i) { oa[i] = s_frag_off<AL>(wr * 64 + i * 32, lane); ob[i] = s_frag_off<BL>(wc * 64 + i * 32, lane); }
 
     auto tile_mma = [&](const __bf16* As, const __bf16* Bs) {
         sbf16x8 a[3][2], b[3][2];
@@ -182,8 +210,8 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                a[pl][i] = *reinterpret_cast<const sbf16x8*>(As + pl * SPLANE + oa[i]);
-                b[pl][i] = *reinterpret_cast<const sbf16x8*>(Bs + pl * SPLANE + ob[i]);
+                a[pl][i] = s_frag<AL>(As + pl * PLA, oa[i]);
+                b[pl][i] = s_frag<BL>(Bs + pl * PLB, ob[i]);
             }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -209,13 +237,13 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
         for (int u = 0; u < PD; ++u) {
             const int t = t0 + u;
             const int cur = t & 1;
-            tile_mma(smem[cur][0], smem[cur][1]);
-            s_r2s<AL>(smem[cur ^ 1][0], tid, sa[(u + 1) % PD]);
-            s_r2s<BL>(smem[cur ^ 1][1], tid, sb[(u + 1) % PD]);
+            tile_mma(smem[cur], smem[cur] + 3 * PLA);
+            s_r2s<AL>(smem[cur ^ 1], tid, sa[(u + 1) % PD]);
+            s_r2s<BL>(smem[cur ^ 1] + 3 * PLA, tid, sb[(u + 1) % PD]);
             const int k0 = kbeg + (t + 1 + PD) * SBK;
             s_g2r<AL, true>(p.A, p.lda, m0, p.M, k0, kend, tid, sa[(u + 1) % PD]);
             s_g2r<BL, true>(p.B, p.ldb, n0, p.N, k0, kend, tid, sb[(u + 1) % PD]);
-            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);          // fragment reads
+            __builtin_amdgcn_sched_group_barrier(0x100, (AL == LAY_K ? 6 : 12) + (BL == LAY_K ? 6 : 12), 0);   // fragment reads
 #pragma unroll
             for (int k = 0; k < 24; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
@@ -232,11 +260,11 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
             const int t = t0 + u;
             if (t < nk) {
                 const int cur = t & 1;
-                tile_mma(smem[cur][0], smem[cur][1]);
+                tile_mma(smem[cur], smem[cur] + 3 * PLA);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < nk) {
-                    s_r2s<AL>(smem[cur ^ 1][0], tid, sa[(u + 1) % PD]);
-                    s_r2s<BL>(smem[cur ^ 1][1], tid, sb[(u + 1) % PD]);
+                    s_r2s<AL>(smem[cur ^ 1], tid, sa[(u + 1) % PD]);
+                    s_r2s<BL>(smem[cur ^ 1] + 3 * PLA, tid, sb[(u + 1) % PD]);
                 }
                 fetch(t + 1 + PD, sa[(u + 1) % PD], sb[(u + 1) % PD]);
                 __syncthreads();
@@ -244,7 +272,7 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
         }
     }
 
-    gemm_epilogue<EPI>(p, acc, reinterpret_cast<float*>(&smem[0][0][0]), m0, n0, tile_m);
+    gemm_epilogue<EPI>(p, acc, reinterpret_cast<float*>(&smem[0][0]), m0, n0, tile_m);
 }
 
 }  // namespace btvae_gemm
