@@ -328,7 +328,8 @@ def main():
                          "algorithmic_bytes": 4.0 * (S * B * 1000 + 1000 * 1000 + S * B * 1000),
                          "fwd_family_tflops": fwd_fl / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else None,
                          "all_gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None,
-                         "step_model_tflops": flops_per_sample(S) * B / (ms_step * 1e-3) / 1e12},
+                         "step_model_tflops": flops_per_sample(S) * B / (ms_step * 1e-3) / 1e12,
+                         "step_frac_of_fp32_mfma_peak": flops_per_sample(S) * B / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
             "kernels": kernels,
             "kernels_note": f"per kernel family, HIP events around every launch of {BREAKDOWN_STEPS} extra steps after the timed region",
             "last_loss": last,
