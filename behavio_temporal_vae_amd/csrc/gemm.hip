@@ -262,13 +262,27 @@ __global__ __launch_bounds__(256, BTVAE_GEMM_MINWG) void gemm_f32_mfma(const Gem
     gemm_epilogue<EPI>(p, acc, &smem[0][0][0], m0, n0, tile_m);   // the k-loop's last barrier has retired all tile reads
 }
 
+// sum of the z slabs of element i; four independent partial sums keep several loads in flight
+__device__ __forceinline__ float slab_sum(const float* __restrict__ slabs, size_t i, int nslab, size_t stride) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+#pragma unroll 2
+    for (; z + 4 <= nslab; z += 4) {
+        s0 += slabs[(size_t)z * stride + i];
+        s1 += slabs[(size_t)(z + 1) * stride + i];
+        s2 += slabs[(size_t)(z + 2) * stride + i];
+        s3 += slabs[(size_t)(z + 3) * stride + i];
+    }
+    for (; z < nslab; ++z) s0 += slabs[(size_t)z * stride + i];
+    return (s0 + s1) + (s2 + s3);
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t n, int nslab, size_t stride, int accumulate) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += step) {
-        float v = accumulate ? out[i] : 0.f;
-        for (int z = 0; z < nslab; ++z) v += slabs[(size_t)z * stride + i];
-        out[i] = v;
+        const float v = slab_sum(slabs, i, nslab, stride);
+        out[i] = accumulate ? out[i] + v : v;
     }
 }
 
@@ -279,8 +293,7 @@ __global__ void slab_reduce_affine_kernel(const float* __restrict__ slabs, float
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += step) {
-        float v = 0.f;
-        for (int z = 0; z < nslab; ++z) v += slabs[(size_t)z * stride + i];
+        float v = slab_sum(slabs, i, nslab, stride);
         const int k = (int)(i % (size_t)K);
         const size_t r = i / (size_t)K;
         v = fmaf(scale[k], v, shift[k] * rowv[r]);
