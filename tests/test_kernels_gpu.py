@@ -438,3 +438,35 @@ def test_linear_products_bf16_operands(dev, M, N, K):
         blk = yy[t * 128:(t + 1) * 128]
         assert torch.allclose(part[t, 0].cpu().double(), blk.mean(0), rtol=1e-4, atol=1e-5)
         assert torch.allclose(part[t, 1].cpu().double(), ((blk - blk.mean(0)) ** 2).sum(0), rtol=1e-3, atol=1e-4)
+
+
+def test_linear_products_at_benchmark_size(dev, gemm_mode):
+    """The three Linear products at the benchmark's decoder shape (M = S*B = 65536, N = K = 1000): forward rows and
+    dgrad rows sampled against fp64 on the CPU (2e-6 relative + 2e-6*sqrt(reduction length) absolute, as at small
+    sizes), BatchNorm statistics and the whole weight gradient against fp64 products on the device."""
+    M, N, K = 65536, 1000, 1000
+    g = torch.Generator(device=dev).manual_seed(11)
+    X = torch.randn(M, K, device=dev, generator=g)
+    W = torch.randn(N, K, device=dev, generator=g) * 0.03
+    b = torch.randn(N, device=dev, generator=g)
+    Y = torch.empty(M, N, device=dev)
+    part = torch.empty((M + 127) // 128, 2, N, device=dev)
+    nv.call("btvae_linear_relu_stats_fwd", P(X), K, P(W), P(b), P(Y), P(part), M, K, N)
+    rows = torch.randint(0, M, (96,), generator=torch.Generator().manual_seed(3)).tolist() + [0, 127, 128, M - 1]
+    ref = torch.relu(X[rows].cpu().double() @ W.cpu().double().t() + b.cpu().double())
+    close(Y[rows], ref, 2e-6, 2e-6 * math.sqrt(K), "forward rows")
+    mean, inv = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    nv.call("btvae_bn_stats_finalize", P(part), (M + 127) // 128, M, N, P(mean), P(inv), None, None, 0.1, 1e-5)
+    Yd = Y.double()
+    close(mean, Yd.mean(0), 1e-5, 1e-6, "column mean")
+    close(inv, 1.0 / torch.sqrt(Yd.var(0, unbiased=False) + 1e-5), 1e-5, 0.0, "column invstd")
+    dY = torch.randn(M, N, device=dev, generator=g)
+    dX = torch.empty(M, K, device=dev)
+    nv.call("btvae_linear_dgrad", P(dY), P(W), None, P(dX), K, M, N, K)
+    close(dX[rows], dY[rows].cpu().double() @ W.cpu().double(), 2e-6, 2e-6 * math.sqrt(N), "dgrad rows")
+    dW = torch.empty(N, K, device=dev)
+    ws = torch.empty(32 * 1024 * 1024, device=dev)
+    nv.call("btvae_linear_wgrad", P(dY), P(X), K, P(dW), P(ws), ws.numel(), M, N, K, 0)
+    # sums of 65536 unit-variance products (result rms 256) accumulated in fp32, 4096 terms per split: every add rounds
+    # a running sum of magnitude ~64, a random walk of a few 1e-4 per split; 1.2e-5 of the result's rms is the bound
+    close(dW, dY.double().t() @ X.double(), 2e-6, 1.2e-5 * math.sqrt(M), "wgrad")
