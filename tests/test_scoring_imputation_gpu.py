@@ -3,6 +3,7 @@ by substituting ``torch.randn`` with the recorded draws), size-independent prope
 training entry point end to end on synthetic data."""
 import json
 import math
+import os
 
 import numpy as np
 import pytest
@@ -304,3 +305,57 @@ def test_streamed_test_metrics_vs_reference(dev, tmp_path):
         a = pickle.load(f)
     assert set(a["test"]) == {"loglikelihood", "error_l_1", "error_l_2"}
     assert abs(a["test"]["error_l_2"] - float(g["l_2"].mean())) <= 1e-4 * abs(float(g["l_2"].mean()))
+
+
+def test_collection_scripts_end_to_end(dev, tmp_path):
+    """Both evaluation CLIs on a saved run folder (trained_model.pt + config.json + conditioner.pkl) and an .npz test
+    split: the files, columns and keys the reference's scripts write (scripts/collect_testing_results.py:117-137,
+    scripts/collect_imputation_results.py:112-148), and the imputation errors recomputed from the saved samples."""
+    import importlib.util
+    import pickle
+    import types
+    import pandas as pd
+    g = load_golden("test_metrics_tiny")
+    cond, cset = make_cond(g)
+    m = build(g, dev, cond)
+    run = tmp_path / "runs" / "run0"
+    run.mkdir(parents=True)
+    m.save(str(run), device=str(dev))
+    cond.save(str(run))
+    with open(run / "config.json", "w") as f:
+        json.dump({"model": json.loads(str(g["model_cfg"]))}, f)
+    (tmp_path / "runs" / "not_a_run").mkdir()
+    N, D = int(g["N"]), int(g["D"])
+    npz = tmp_path / "test.npz"
+    np.savez(npz, X_test=g["x"], user_ids=np.arange(N) // 3, months=g["months"][:, 0], cond_months=g["months"], cond_weekdays=g["weekdays"])
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(__file__), "..", "scripts", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    common = dict(config_dir=str(tmp_path / "runs"), test_npz=str(npz), overwrite=True, device=str(dev))
+    done = load("collect_testing_results").main(types.SimpleNamespace(num_rec_samples=6, batch_size=5, batch_size_mc=4, **common))
+    assert set(done) == {"run0"}
+    raw = pd.read_csv(run / "test_results_raw.csv")
+    assert list(raw.columns) == ["l_1", "l_2", "loglikelihood", "user_id", "month", "set_type"] and len(raw) == N
+
+    W = D // 2
+    args = types.SimpleNamespace(num_imputation_samples=4, batch_size=5, unobserved_window_length=W, num_pseudo_gibbs_steps=6,
+                                 num_metropolis_within_hasting_steps=0, **common)
+    done = load("collect_imputation_results").main(args)
+    assert set(done) == {"run0"} and set(done["run0"]) == {"loglikelihood", "error_l_1", "error_l_2"}
+    sub = run / f"forecasting_results_{W}"
+    raw = pd.read_csv(sub / "test_results_raw.csv")
+    assert list(raw.columns) == ["l_1", "l_2", "loglikelihood", "user_id", "month", "set_type"] and len(raw) == N
+    assert np.isfinite(raw[["l_1", "l_2", "loglikelihood"]].values).all()
+    with open(sub / "test_results_aggregate.pkl", "rb") as f:
+        agg = pickle.load(f)
+    assert abs(agg["test"]["error_l_1"] - raw["l_1"].mean()) < 1e-5 * abs(raw["l_1"].mean())
+    with open(sub / "test_results_samples.pkl", "rb") as f:
+        smp = pickle.load(f)
+    assert smp["test"].shape == (N, W)
+    # second call without overwrite skips the folder
+    args.overwrite = False
+    assert load("collect_imputation_results").main(args) == {}
