@@ -345,9 +345,11 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
     return dx
 
 
-def net_backward(plan: NetPlan, tape: NetTape, draw: Dict[str, torch.Tensor], need_input_grad: bool, accumulate: bool = False):
+def net_backward(plan: NetPlan, tape: NetTape, draw: Dict[str, torch.Tensor], need_input_grad: bool, accumulate: bool = False,
+                 after_heads=None):
     """Backward through heads and trunk given dL/d(raw head outputs).  Parameter gradients are written
-    (or accumulated) into the ``.grad`` views of the model's gradient arena."""
+    (or accumulated) into the ``.grad`` views of the model's gradient arena.  ``after_heads()`` is called once every
+    head's gradients are enqueued (data-parallel training starts reducing them while the trunk backward runs)."""
     g_trunk = None
     for name, units in plan.heads.items():
         d = draw[name]
@@ -368,6 +370,8 @@ def net_backward(plan: NetPlan, tape: NetTape, draw: Dict[str, torch.Tensor], ne
             first = i == 0
             g = _unit_backward(units[i], svs[i], g, g_trunk if first else None, True, accumulate)
         g_trunk = g
+    if after_heads is not None:
+        after_heads()
     g = g_trunk
     for i in range(len(plan.trunk) - 1, -1, -1):
         g = _unit_backward(plan.trunk[i], tape.trunk[i], g, None, need_input_grad or i > 0, accumulate)

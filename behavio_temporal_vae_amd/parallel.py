@@ -1,8 +1,8 @@
 """Data-parallel plumbing over ``torch.distributed`` (backend "nccl" = RCCL over xGMI on MI355X; "gloo" in CPU tests).
 
 The path shards by data.  Training: every rank holds the full 41.6 MB of weights and a slice of the global batch;
-the flat gradient arena is all-reduced in two spans (decoder first, while the encoder backward still runs), then
-averaged, before the fused clip + Adam step — so clipping sees the same averaged gradient a single-device step on
+the flat gradient arena is all-reduced in four spans as their gradients become final (each network's heads, then
+its trunk; everything but the encoder trunk overlaps later backward work), then averaged, before the fused clip + Adam step — so clipping sees the same averaged gradient a single-device step on
 the global batch would.  Scoring / imputation: profiles are split into contiguous per-rank ranges and the only
 collective is one reduce of (sum of log-likelihoods, count).
 """

@@ -181,6 +181,16 @@ class VAE(torch.nn.Module):
                 p.grad = grads[o:o + p.numel()].view(p.shape)
         self._arena, self._grad_arena, self._enc_span = arena, grads, enc_span
         self._offsets = offs
+        # per network: (start, trunk start, trunk end, end) of its slice of the arenas; the trunk's parameters are
+        # contiguous, everything else of the network (heads, dictionary) has its gradient ready before the trunk's
+        self._net_spans = {}
+        for name, net, lo, hi in (("encoder", self.encoder, 0, enc_span), ("decoder", self.decoder, enc_span, off)):
+            trunk = {id(q) for q in net.parameterizer.block_dict["input"].parameters()}
+            t_offs = [(o, o + (q.numel() + 3) // 4 * 4) for q, o in zip(params, offs) if id(q) in trunk]
+            t0, t1 = min(a for a, _ in t_offs), max(b for _, b in t_offs)
+            if sum(b - a for a, b in t_offs) != t1 - t0:
+                t0, t1 = lo, hi           # trunk not contiguous in parameters() order: reduce the network as one span
+            self._net_spans[name] = (lo, t0, t1, hi)
         ref = weakref.ref(self)
         for net in (self.encoder, self.decoder):
             object.__setattr__(net, "_arena_owner", ref)
@@ -381,13 +391,14 @@ class VAE(torch.nn.Module):
             if "sigma" in fw.dec_tape.dfac:
                 draw["sigma"] = dsig
         out = E.elbo_scalars(logp, fw.klrow, beta)
-        dzc = E.net_backward(dec.plan(), fw.dec_tape, draw, need_input_grad=True)
-        self._grads_ready("decoder")
+        dzc = E.net_backward(dec.plan(), fw.dec_tape, draw, need_input_grad=True, after_heads=lambda: self._grads_ready("decoder", "heads"))
+        self._grads_ready("decoder", "trunk")
         R = fw.post["mu"].shape[0]
         dm, ds = E.reparam_kl_bwd(dzc, fw.eps, fw.post["mu"], fw.post["sigma"], fw.post_dfac["mu"], fw.post_dfac["sigma"],
                                   fw.S, fw.three_d, self.condition_dim, beta / R)
-        E.net_backward(self.encoder.plan(), fw.enc_tape, {"mu": dm, "sigma": ds}, need_input_grad=False)
-        self._grads_ready("encoder")
+        E.net_backward(self.encoder.plan(), fw.enc_tape, {"mu": dm, "sigma": ds}, need_input_grad=False,
+                       after_heads=lambda: self._grads_ready("encoder", "heads"))
+        self._grads_ready("encoder", "trunk")
         return out
 
     # ------------------------------------------------------------------ data parallel hooks
@@ -402,11 +413,18 @@ class VAE(torch.nn.Module):
         self._dp_world = self._dp_sync.world
         E.BN_SYNC = BatchNormSync(process_group) if (sync_batchnorm and self._dp_world > 1) else None
 
-    def _grads_ready(self, which: str):
+    def _grads_ready(self, which: str, part: str):
+        """Start the sum all-reduce of the gradients that have just been enqueued: a network's heads (and the decoder's
+        dictionary) once their backward is issued, its trunk after the trunk's."""
         if self._dp_world <= 1:
             return
-        n = self._grad_arena.numel()
-        self._dp_sync.launch(self._grad_arena[self._enc_span:n] if which == "decoder" else self._grad_arena[:self._enc_span])
+        lo, t0, t1, hi = self._net_spans[which]
+        if part == "trunk":
+            self._dp_sync.launch(self._grad_arena[t0:t1])
+        else:
+            for a, b in ((lo, t0), (t1, hi)):
+                if b > a:
+                    self._dp_sync.launch(self._grad_arena[a:b])
 
     def _dp_finish(self, scalars: torch.Tensor):
         if self._dp_world <= 1:
