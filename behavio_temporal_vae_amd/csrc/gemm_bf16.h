@@ -2,10 +2,10 @@
 //
 // Operands stay fp32 in HBM: they are rounded to bf16 (round-to-nearest-even) on the way into LDS, so no tensor
 // changes its storage format and the fp32 kernel remains a drop-in alternative.  128x128x32 block tile, 4 waves
-// (2x2) of 64x64, double-buffered LDS, one barrier per k-tile.  Every LDS operand image is [128 rows][32 k] bf16,
-// k-contiguous with an 80-byte row stride, whatever the global layout: k-contiguous operands are packed eight k
-// at a time into one 16-byte LDS store, m/n-contiguous operands are transposed in registers (each thread owns a
-// 4k x 4m patch) into four 8-byte stores.  A fragment for one MFMA is then a single 16-byte LDS read for both.
+// (2x2) of 64x64, double-buffered LDS, one barrier per k-tile.  k-contiguous operands: LDS image [128 rows][32 k] bf16
+// with an 80-byte row stride, four k per 8-byte store (8 lanes read one row's 128 bytes), one 16-byte read per MFMA operand.
+// m/n-contiguous operands keep their orientation: image [32 k][128 m] with a 320-byte row pitch, 8-byte stores of
+// four m, and the MFMA operand gathered by two transposing LDS reads (ds_read_b64_tr_b16).
 // With fp32 operands the kernel is bound by L2->CU bytes (1 KiB of operands per 32 KiFLOP), not by the matrix pipe.
 #pragma once
 #include "gemm_common.h"
@@ -15,6 +15,10 @@ namespace btvae_gemm {
 constexpr int HBK = 32;              // k elements per tile
 constexpr int HLD = HBK + 8;         // LDS row stride in bf16 elements (80 B): 16-byte reads and stores conflict-free
 constexpr int HTILE = 128 * HLD;     // bf16 elements per operand tile
+constexpr int HMP = 160;             // m-contiguous operands: bf16 elements between k rows (conflict-free transposing reads)
+static_assert(HBK * HMP == HTILE, "both operand images take the same LDS");
+typedef short hs16x4 __attribute__((ext_vector_type(4)));
+typedef short hs16x8 __attribute__((ext_vector_type(8)));
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -25,9 +29,9 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
 }
 
-// thread -> patch maps.  LAY_K: two 8-k chunks per thread; rows of neighbouring 4-lane groups are 4 apart so the
-// two rows an 8-lane store group touches fall in different halves of the 32 LDS store banks.
-__device__ __forceinline__ int hk_row(int f) { const int rr = f >> 2; return (rr & ~5) | ((rr & 1) << 2) | ((rr >> 2) & 1); }
+// thread -> patch maps.  LAY_K: four 4-k chunks per thread, 8 lanes per row; rows of neighbouring 8-lane groups are 4
+// apart so the two rows a 16-lane store group touches fall in different halves of the 32 LDS store banks.
+__device__ __forceinline__ int hk_row(int f) { const int rr = f >> 3; return (rr & ~5) | ((rr & 1) << 2) | ((rr >> 2) & 1); }
 
 struct Stage { float v[16]; };   // 16 staged fp32 values per thread and operand (kept in registers)
 
@@ -40,22 +44,17 @@ __device__ __forceinline__ void h_g2r(const float* __restrict__ P, int ld, int r
                                       int tid, Stage& st) {
     if (LAY == LAY_K) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < 4; ++q) {        // 8 lanes read one row's 128 contiguous bytes; v[4q + i] = (row hk_row(f), k = 4(f&7) + i)
             const int f = tid + 256 * q;
-            const int gr = row0 + hk_row(f), gk = k0 + ((f & 3) << 3);
+            const int gr = row0 + hk_row(f), gk = k0 + ((f & 7) << 2);
             const float* src = P + (size_t)min(gr, nrows - 1) * ld + gk;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            if (FULL) {
-                a = *reinterpret_cast<const float4*>(src);
-                b = *reinterpret_cast<const float4*>(src + 4);
-            } else {
-                if (gr < nrows && gk + 3 < kend) a = *reinterpret_cast<const float4*>(src);
-                if (gr < nrows && gk + 7 < kend) b = *reinterpret_cast<const float4*>(src + 4);
-            }
-            put4(st, 2 * q, a); put4(st, 2 * q + 1, b);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FULL) a = *reinterpret_cast<const float4*>(src);
+            else if (gr < nrows && gk + 3 < kend) a = *reinterpret_cast<const float4*>(src);
+            put4(st, q, a);
         }
     } else {
-        const int kq = tid & 7, mq = tid >> 3;
+        const int mq = tid & 31, kq = tid >> 5;          // a 32-lane half reads 512 contiguous bytes of one k row
         const int gm = row0 + (mq << 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -73,19 +72,30 @@ __device__ __forceinline__ void h_r2s(__bf16* S, int tid, const Stage& st) {
     const float* v = st.v;
     if (LAY == LAY_K) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < 4; ++q) {
             const int f = tid + 256 * q;
-            const float* w = v + 8 * q;
-            *reinterpret_cast<uint4*>(S + hk_row(f) * HLD + ((f & 3) << 3)) =
-                make_uint4(pack_bf16(w[0], w[1]), pack_bf16(w[2], w[3]), pack_bf16(w[4], w[5]), pack_bf16(w[6], w[7]));
+            const float* w = v + 4 * q;
+            *reinterpret_cast<uint2*>(S + hk_row(f) * HLD + ((f & 7) << 2)) = make_uint2(pack_bf16(w[0], w[1]), pack_bf16(w[2], w[3]));
         }
     } else {
-        const int kq = tid & 7, mq = tid >> 3;
-        __bf16* dst = S + (mq << 2) * HLD + (kq << 2);
+        const int mq = tid & 31, kq = tid >> 5;
+        __bf16* dst = S + (kq << 2) * HMP + (mq << 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)      // row m = 4mq + i gets its four k values
-            *reinterpret_cast<uint2*>(dst + i * HLD) = make_uint2(pack_bf16(v[i], v[4 + i]), pack_bf16(v[8 + i], v[12 + i]));
+        for (int j = 0; j < 4; ++j)      // k row 4kq + j gets its four m values
+            *reinterpret_cast<uint2*>(dst + j * HMP) = make_uint2(pack_bf16(v[4 * j], v[4 * j + 1]), pack_bf16(v[4 * j + 2], v[4 * j + 3]));
     }
+}
+
+// MFMA operand of k step s (16 k) for the 32-row block at `blk`: row = lane & 31, k = 16s + 8*(lane>>5) .. +7.
+// Every lane must be active at the transposing reads.
+template <int LAY>
+__device__ __forceinline__ bf16x8 h_frag(const __bf16* S, int blk, int s, int lane) {
+    if (LAY == LAY_K) return *reinterpret_cast<const bf16x8*>(S + (blk + (lane & 31)) * HLD + s * 16 + (lane >> 5) * 8);
+    typedef __attribute__((address_space(3))) hs16x4 lds_s16x4;
+    const __bf16* q = S + (s * 16 + 8 * (lane >> 5) + ((lane & 15) >> 2)) * HMP + blk + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const hs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)q);
+    const hs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q + 4 * HMP));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 template <int AL, int BL, int EPI>
@@ -93,7 +103,6 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_mfma(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[2][2][HTILE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
-    const int li = lane & 31, lh = lane >> 5;
 
     int bid = blockIdx.x;
     {
@@ -130,8 +139,8 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_mfma(const GemmArgs p) {
             bf16x8 a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const bf16x8*>(As + (wr * 64 + i * 32 + li) * HLD + s * 16 + lh * 8);
-                b[i] = *reinterpret_cast<const bf16x8*>(Bs + (wc * 64 + i * 32 + li) * HLD + s * 16 + lh * 8);
+                a[i] = h_frag<AL>(As, wr * 64 + i * 32, s, lane);
+                b[i] = h_frag<BL>(Bs, wc * 64 + i * 32, s, lane);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
