@@ -191,12 +191,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    # Rehearsal on a one-GPU box: BTVAE_BENCH_BACKEND=gloo with BTVAE_BENCH_ONE_GPU=1 runs every rank on device 0
+    # (RCCL refuses two ranks on one device); it exercises the multi-rank control flow, not the collectives' speed.
+    if os.environ.get("BTVAE_BENCH_ONE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
+    backend = os.environ.get("BTVAE_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from behavio_temporal_vae_amd import _native as nv
     from behavio_temporal_vae_amd.vae_models import CVAE
