@@ -180,6 +180,9 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         raise RuntimeError("a residual unit needs its input materialised")
     x, W, b, x_sc, x_sh = _linear_operands(u.lin, x)
     if u.bn is not None and train:
+        if M * (BN_SYNC.world if BN_SYNC is not None else 1) <= 1:
+            # torch.nn.BatchNorm1d refuses a one-row batch in train mode (torch/nn/functional.py, _verify_batch_size)
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([{M}, {N}])")
         tiles = (M + 127) // 128
         y = torch.empty(M, N, device=dev)
         part = WS.get("bnpart", tiles * 2 * N, dev)

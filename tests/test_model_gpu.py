@@ -420,3 +420,17 @@ def test_module_api_with_stock_optimizer(dev):
             ma.loss(x, xd["params"], zd["params"], beta=0.7, prior_params=ma.prior_params)["loss"].backward()
         grads.append(ma._grad_arena.clone())
     assert torch.allclose(grads[1], 2 * grads[0], rtol=2e-3, atol=1e-6)
+
+
+def test_single_row_batch_in_train_mode_raises_like_batchnorm(dev):
+    """A one-profile batch in train mode: torch's BatchNorm1d raises ValueError on the encoder's single row, and so
+    does this path; eval mode accepts it."""
+    g = load_golden("tiny_dict_2d")
+    m = build(g, dev).train()
+    x, c = T(g["steps_x"][0][:1]).to(dev), T(g["steps_c"][0][:1]).to(dev)
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        m.forward(x, c, num_mc_samples=3)
+    m.eval()
+    with torch.no_grad():
+        out, post = m.forward(x, c, num_mc_samples=3)
+    assert out["params"]["mu"].shape[:2] == (3, 1) and torch.isfinite(out["params"]["mu"]).all()
