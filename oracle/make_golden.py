@@ -229,21 +229,23 @@ def case_config0_shape(name="config0_smallbatch", seed=2112, B=64, S=4, steps=3)
 
 
 class DrawLog:
-    """Records every torch.randn / torch.randn_like result while active."""
+    """Records every torch.randn / torch.randn_like / torch.rand result while active."""
     def __init__(self):
-        self.randn, self.randn_like = [], []
+        self.randn, self.randn_like, self.rand = [], [], []
 
     def __enter__(self):
-        self._r, self._rl = torch.randn, torch.randn_like
+        self._r, self._rl, self._u = torch.randn, torch.randn_like, torch.rand
         def randn(*a, **k):
             t = self._r(*a, **k); self.randn.append(t.clone()); return t
         def randn_like(*a, **k):
             t = self._rl(*a, **k); self.randn_like.append(t.clone()); return t
-        torch.randn, torch.randn_like = randn, randn_like
+        def rand(*a, **k):
+            t = self._u(*a, **k); self.rand.append(t.clone()); return t
+        torch.randn, torch.randn_like, torch.rand = randn, randn_like, rand
         return self
 
     def __exit__(self, *exc):
-        torch.randn, torch.randn_like = self._r, self._rl
+        torch.randn, torch.randn_like, torch.rand = self._r, self._rl, self._u
 
 
 def case_scoring(name="scoring_tiny", seed=5, N=20, K=7, D=6):
@@ -372,6 +374,55 @@ def case_imputation(name="imputation_tiny", seed=9, N=10, D=6, W=3, T=5, num_sam
     print("wrote", name)
 
 
+def case_imputation_mh(name="imputation_mh_tiny", seed=21, N=9, D=6, W=3, T_pg=2, T_mh=4, num_samples=3):
+    """Pseudo-Gibbs warm-up followed by Metropolis-within-Gibbs sweeps (src/imputation_lib.py:100-156,158-189) in one
+    batch, every draw logged in call order: normal draws by shape, the acceptance uniforms, and the acceptance
+    decisions' margins so that a replay in fp32 on another device cannot flip one."""
+    rng = np.random.default_rng(seed)
+    cfg = tiny_model_cfg("dict-gauss")
+    cond, cset = make_conditioner(N, rng)
+    torch.manual_seed(seed)
+    model = CVAE(input_dim=D, conditioner=cond, **cfg)
+    model.train()
+    with torch.no_grad():
+        for _ in range(3):
+            model.forward(torch.tensor(synth_profiles(16, D, rng)), torch.tensor(rng.normal(size=(16, 4)).astype(np.float32)), num_mc_samples=2)
+    model.eval()
+    X = synth_profiles(N, D, rng)
+    x_missing = X.copy()
+    x_missing[:, -W:] = np.nan
+    rhos = []
+    orig_min = torch.minimum
+    def minimum(a, b):
+        r = orig_min(a, b); rhos.append(r.clone()); return r
+    torch.manual_seed(seed + 1)
+    torch.minimum = minimum
+    try:
+        with DrawLog() as log:
+            cs, cm, cc, _, _ = imputation_lib.cvae_imputation(model, x_missing, cond, cset, num_samples=num_samples,
+                                                              num_iter=T_mh, warmup_steps=T_pg, device="cpu")
+    finally:
+        torch.minimum = orig_min
+    u = np.stack([t.numpy() for t in log.rand])                       # [T_mh, N]
+    rho = np.stack([t.numpy() for t in rhos])                         # [T_mh, N]
+    margin = float(np.abs(u - rho).min())
+    assert margin > 2e-3, f"an acceptance decision sits {margin} from its threshold: pick another seed"
+    out = {"model_cfg": json.dumps(cfg), "D": D, "N": N, "W": W, "T_pg": T_pg, "T_mh": T_mh, "num_samples": num_samples,
+           "x_missing": x_missing, "c": cond.transform(cset).astype(np.float32),
+           "randn_shapes": json.dumps([list(t.shape) for t in log.randn]),
+           "randn_like_shapes": json.dumps([list(t.shape) for t in log.randn_like]),
+           "accept_u": u, "accept_rho": rho, "accepted": (u < rho),
+           "cond_samples": cs.numpy(), "cond_mean": cm.numpy(), "cond_cov": cc.numpy()}
+    for i, t in enumerate(log.randn):
+        out[f"randn_{i}"] = t.numpy()
+    for i, t in enumerate(log.randn_like):
+        out[f"randn_like_{i}"] = t.numpy()
+    out.update(np_state(model.state_dict()))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, "randn", [list(t.shape) for t in log.randn], "randn_like", [list(t.shape) for t in log.randn_like],
+          "accept rate", float((u < rho).mean()), "margin", margin)
+
+
 def case_pointwise(name="pointwise"):
     xs = torch.tensor([-30.0, -10.0, -1.0, 0.0, 1.0, 4.9, 5.0, 5.0001, 5.1, 10.0, 40.0])
     out = {"softplus_in": xs.numpy(), "softplus_out": ref_utils.to_sigma(xs).numpy()}
@@ -413,6 +464,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":      # only the test-metrics case
         case_test_metrics()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "mh":           # only the Metropolis-within-Gibbs case
+        case_imputation_mh()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "nobn":         # only the case without BatchNorm
         case_forward_train("tiny_nobn_2d", "dict-gauss", seed=8, B=16, dropout=True, bn=False)
         sys.exit(0)
@@ -426,4 +480,5 @@ if __name__ == "__main__":
     case_scoring()
     case_test_metrics()
     case_imputation()
+    case_imputation_mh()
     case_config0_shape()

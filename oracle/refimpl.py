@@ -520,6 +520,60 @@ def pseudo_gibbs(sd: Dict[str, Tensor], spec: ModelSpec, x0: Tensor, missing_mas
     return cs, cm, cc, x
 
 
+def metropolis_within_gibbs(sd: Dict[str, Tensor], spec: ModelSpec, x0: Tensor, missing_mask: Tensor, c: Tensor,
+                            eps_z0: Tensor, eps_prop: Tensor, eps_x: Tensor, accept_u: Tensor, num_samples: int):
+    """Metropolis-within-Gibbs sweeps with injected noise (src/imputation_lib.py:100-156, deterministic conditions,
+    dictionary-Gaussian decoder, eval-mode networks).
+
+    State z starts as a posterior draw (``eps_z0[B,L]``, :109).  Sweep t: posterior q(z|x,c) from the current x
+    (:125), decoder at the current z (:127), proposal z' = mu + sigma*eps_prop[t] from the same posterior (:133),
+    weights w(z) = log p(x|z) + log p(z) - log q(z|x) (:137-139), accept row b iff ``accept_u[t,b] < min(1, exp(w' - w))``
+    (:143-147), then one conditional draw of the missing coordinates from the decoder at the (possibly updated) z
+    (``eps_x[t]``, :151) written back by the row-major masked scatter (:153); ring slot ``t % num_samples``.
+    Returns (cond_samples, cond_mean, cond_cov, accepted[T,B] bool, x_final)."""
+    x = x0.clone()
+    T, B = eps_prop.shape[0], x.shape[0]
+    observed = torch.where(~missing_mask[0])[0].tolist()
+    obs, un = split_indices(spec.input_dim, observed)
+    Un = len(un)
+    cs = torch.zeros(num_samples, B, Un, dtype=x.dtype)
+    cm = torch.zeros(num_samples, B, Un, dtype=x.dtype)
+    cc = torch.zeros(num_samples, B, Un, Un, dtype=x.dtype)
+    U = sd["decoder.SigmaMapper"]
+    accepted = torch.zeros(T, B, dtype=torch.bool)
+
+    def posterior():
+        return dist_forward(sd, "encoder", spec.enc, torch.cat((x, c), -1), False)
+
+    def decode(zz):
+        return dist_forward(sd, "decoder", spec.dec, torch.cat((zz, c), -1), False)
+
+    def weight(zz, lik, post):
+        return (decoder_log_likelihood(sd, spec.dec, x, lik)
+                + normal_log_prob(zz, torch.zeros_like(zz), torch.ones_like(zz)).sum(-1)
+                - normal_log_prob(zz, post["mu"], post["sigma"]).sum(-1))
+
+    p0 = posterior()
+    z = p0["mu"] + p0["sigma"] * eps_z0
+    for t in range(T):
+        post = posterior()
+        lik = decode(z)
+        z_prop = post["mu"] + post["sigma"] * eps_prop[t]
+        lik_prop = decode(z_prop)
+        log_ratio = weight(z_prop, lik_prop, post) - weight(z, lik, post)
+        rho = torch.minimum(torch.ones(()), torch.exp(log_ratio))
+        acc = accept_u[t] < rho
+        accepted[t] = acc
+        z = torch.where(acc[:, None], z_prop, z)
+        lik = {k: torch.where(acc[:, None], lik_prop[k], lik[k]) for k in lik}
+        mean, cov = conditional_params(U, spec.dec, lik["mu"], lik["sigma"], x[:, obs], obs)
+        samp = mean + (torch.linalg.cholesky(cov) @ eps_x[t][..., None])[..., 0]
+        slot = t % num_samples
+        cs[slot], cm[slot], cc[slot] = samp, mean, cov
+        x[missing_mask] = samp.flatten()
+    return cs, cm, cc, accepted, x
+
+
 def mixture_loglik(cond_mean: Tensor, cond_cov: Tensor, target: Tensor) -> Tensor:
     """Held-out log-likelihood under the equal-weight mixture of the stored conditional Gaussians
     (src/imputation_lib.py:230-231): logsumexp_k log N(target; mean_k, cov_k) − log K."""

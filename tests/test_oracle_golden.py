@@ -177,3 +177,32 @@ def test_imputation():
         lls.append(R.mixture_loglik(cm, cc, T(g["target"])[b0:b0 + bs]))
         assert np.allclose(cs.numpy(), g["samples"][:, b0:b0 + bs], rtol=2e-4, atol=2e-5)
     assert rel_err(torch.cat(lls).numpy(), g["loglik"]) < 2e-4
+
+
+def test_metropolis_within_gibbs():
+    """Warm-up by pseudo-Gibbs, hand-over through ring slot ``warmup % num_samples`` (src/imputation_lib.py:172), then
+    Metropolis-within-Gibbs with the reference's draws: identical accept decisions, same conditional buffers."""
+    import json
+    g = load_golden("imputation_mh_tiny")
+    spec, _ = golden_spec(g)
+    sd = golden_state(g)
+    N, W, L, ns = int(g["N"]), int(g["W"]), spec.latent_dim, int(g["num_samples"])
+    Tpg, Tmh = int(g["T_pg"]), int(g["T_mh"])
+    shapes = json.loads(str(g["randn_shapes"]))
+    like_shapes = json.loads(str(g["randn_like_shapes"]))
+    zs = [T(g[f"randn_{i}"])[0] for i, sh in enumerate(shapes) if sh == [1, N, L]]           # PG x Tpg, MH start, MH proposals
+    xs = [T(g[f"randn_like_{i}"]) for i, sh in enumerate(like_shapes) if sh == [N, W]]        # PG x Tpg, MH x Tmh
+    xm = T(g["x_missing"]).float()
+    mask = torch.isnan(xm)
+    x0 = xm.clone()
+    x0[mask] = x0[~mask].mean()
+    c = T(g["c"])
+    cs, _, _, x_pg = R.pseudo_gibbs(sd, spec, x0, mask, c, torch.stack(zs[:Tpg]), torch.stack(xs[:Tpg]), ns)
+    x1 = x_pg.clone()
+    x1[mask] = cs[Tpg % ns].flatten()
+    cs, cm, cc, acc, _ = R.metropolis_within_gibbs(sd, spec, x1, mask, c, zs[Tpg], torch.stack(zs[Tpg + 1:]), torch.stack(xs[Tpg:]),
+                                                  T(g["accept_u"]), ns)
+    assert np.array_equal(acc.numpy(), g["accepted"])
+    assert np.allclose(cm.numpy(), g["cond_mean"], rtol=2e-4, atol=2e-5)
+    assert np.allclose(cc.numpy(), g["cond_cov"], rtol=2e-4, atol=2e-6)
+    assert np.allclose(cs.numpy(), g["cond_samples"], rtol=2e-4, atol=2e-5)
