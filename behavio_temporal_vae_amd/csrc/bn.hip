@@ -128,6 +128,20 @@ __global__ __launch_bounds__(256) void bn_fold_linear_kernel(const float* __rest
     if (lane == 0) bf[n] = b[n] + acc;
 }
 
+// BatchNorm-backward column sums from the consumers' weight-gradient by-products (btvae_linear_wgrad_affine):
+// sums[0][n] = sum_m G = col_wb[n];  sums[1][n] = sum_m G xhat = invstd[n] (col_wp[n] - mean[n] col_wb[n]).
+__global__ void bn_sums_from_products_kernel(const float* __restrict__ col_wp, const float* __restrict__ col_wb,
+                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                             float* dgamma, float* dbeta, float* __restrict__ sums, int N, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float sb = col_wb[n];
+    const float sg = invstd[n] * (col_wp[n] - mean[n] * sb);
+    sums[n] = sb; sums[N + n] = sg;
+    dbeta[n] = accumulate ? dbeta[n] + sb : sb;
+    dgamma[n] = accumulate ? dgamma[n] + sg : sg;
+}
+
 // ---- forward apply: Out = (Y - mean) * invstd * gamma + beta (+ R) ----
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ Y, const float* __restrict__ mean,
@@ -536,6 +550,17 @@ BTVAE_API int btvae_bn_relu_bwd_sums(const float* G, const float* Y, const float
     else                                 hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, scratch, M, N, rpc);
     colsum_finalize(s, scratch, chunks, 2, N, dbeta, dgamma, sums, sums + N, accumulate);
     return check_launch("bn_relu_bwd_sums");
+}
+
+// First half without a pass over the activations, for a BatchNorm whose output is read only by Linears that ran on
+// its input with folded weights: the sums follow from those Linears' weight-gradient by-products col_wp / col_wb
+// (see btvae_linear_wgrad_affine).  Writes sums[2][N] and (+)= dgamma, dbeta like btvae_bn_relu_bwd_sums.
+BTVAE_API int btvae_bn_bwd_sums_from_products(const float* col_wp, const float* col_wb, const float* mean, const float* invstd,
+                                              float* dgamma, float* dbeta, float* sums, int N, int accumulate, void* stream) {
+    BTVAE_REQUIRE(col_wp && col_wb && mean && invstd && dgamma && dbeta && sums && N > 0, "bn_bwd_sums_from_products: bad argument");
+    hipLaunchKernelGGL(bn_sums_from_products_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, col_wp, col_wb, mean, invstd,
+                       dgamma, dbeta, sums, N, accumulate);
+    return check_launch("bn_bwd_sums_from_products");
 }
 
 // Second half: dPre and dbias from the batch-wide sums (sums[0] = sum g, sums[1] = sum g*xhat over total_rows rows).

@@ -301,6 +301,49 @@ __global__ void slab_reduce_affine_kernel(const float* __restrict__ slabs, float
     }
 }
 
+// Same sum and affine correction with two column reductions over the rows as by-products:
+//   col0[k] = sum_r W[r][k] * P[r][k],  col1[k] = sum_r rowv[r] * W[r][k],  P = sum_z slabs.
+// The grid stride (threads in the grid) is a multiple of K, so a thread only ever meets one column: it keeps that
+// column's two partial sums in registers and writes them once, part[0|1][global thread] (thread g owns column g % K).
+__global__ __launch_bounds__(256) void slab_reduce_affine_cols_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t n, int K,
+                                                                      int nslab, size_t stride, int accumulate,
+                                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                      const float* __restrict__ rowv, const float* __restrict__ W,
+                                                                      float* __restrict__ part) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;          // multiple of K
+    const int k = (int)(g % (size_t)K);
+    const float sc = scale[k], sh = shift[k];
+    float a = 0.f, b = 0.f;
+    for (size_t i = g; i < n; i += step) {
+        const size_t r = i / (size_t)K;
+        const float pv = slab_sum(slabs, i, nslab, stride);
+        const float w = W[i], rv = rowv[r];
+        const float v = fmaf(sc, pv, sh * rv);
+        out[i] = accumulate ? out[i] + v : v;
+        a = fmaf(w, pv, a);
+        b = fmaf(rv, w, b);
+    }
+    part[g] = a;
+    part[step + g] = b;
+}
+
+// col0[k] (+)= sum of part[0][g] over g = k (mod K), col1 likewise from part[1]; one wave per column, fp64 sums
+__global__ __launch_bounds__(256) void cols_finalize_kernel(const float* __restrict__ part, size_t nthreads, int K, float* col0, float* col1,
+                                                            int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= K) return;
+    double a = 0.0, b = 0.0;
+    for (size_t g = (size_t)k + (size_t)lane * K; g < nthreads; g += (size_t)64 * K) { a += part[g]; b += part[nthreads + g]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if (lane == 0) {
+        col0[k] = accumulate ? col0[k] + (float)a : (float)a;
+        col1[k] = accumulate ? col1[k] + (float)b : (float)b;
+    }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 std::atomic<int> g_precision{0};   // 0: fp32 MFMA, 1: bf16 operands, 2: fp32 operands as three bf16 pieces (Linear layers only)
@@ -418,7 +461,8 @@ BTVAE_API int btvae_linear_dgrad(const float* dY, const float* W, const float* R
 // workgroups into slabs held in `ws` and summed by a second kernel.  accumulate != 0 adds to C.
 static int matmul_tn_impl(const float* A, int lda, const float* B, int ldb, float* C, float* ws, long long ws_floats,
                           int M, int N, int K, int accumulate, int prof_kind, hipStream_t s,
-                          const float* scale, const float* shift, const float* rowv) {
+                          const float* scale, const float* shift, const float* rowv,
+                          const float* W = nullptr, float* col_wp = nullptr, float* col_wb = nullptr, int cols_accumulate = 0) {
     GemmArgs a{}; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.ldc = N; a.M = M; a.N = N; a.K = K;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const size_t out_elems = (size_t)M * N;
@@ -435,6 +479,22 @@ static int matmul_tn_impl(const float* A, int lda, const float* B, int ldb, floa
     if (rc) return rc;
     const int nslab = (K + a.kchunk - 1) / a.kchunk;
     const int blocks = (int)std::min<size_t>((out_elems + 255) / 256, 2048);
+    if (scale && W) {
+        // C is [M rows][N columns] here.  Blocks in multiples of N / gcd(256, N) make the grid stride a multiple of N.
+        int gcd = 256, t = N;
+        while (t) { const int q = gcd % t; gcd = t; t = q; }
+        const int unit = N / gcd;
+        const int reps = std::max(1, (int)std::min<size_t>((out_elems + 255) / 256, 2048) / unit);
+        const int cblocks = unit * reps;
+        const size_t nthreads = (size_t)cblocks * 256;
+        const size_t used = (size_t)nslab * out_elems, need = used + 2 * nthreads;
+        BTVAE_REQUIRE((size_t)ws_floats >= need, "linear_wgrad_affine: workspace of %lld floats too small for %zu", ws_floats, need);
+        float* part = ws + used;
+        hipLaunchKernelGGL(slab_reduce_affine_cols_kernel, dim3(cblocks), dim3(256), 0, s, ws, C, out_elems, N, nslab, out_elems,
+                           accumulate, scale, shift, rowv, W, part);
+        hipLaunchKernelGGL(cols_finalize_kernel, dim3((N + 3) / 4), dim3(256), 0, s, part, nthreads, N, col_wp, col_wb, cols_accumulate);
+        return check_launch("matmul_tn.reduce_cols");
+    }
     if (scale) hipLaunchKernelGGL(slab_reduce_affine_kernel, dim3(blocks), dim3(256), 0, s, ws, C, out_elems, nslab, out_elems, accumulate, scale, shift, rowv, N);
     else       hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, C, out_elems, nslab, out_elems, accumulate);
     return check_launch("matmul_tn.reduce");
@@ -452,12 +512,19 @@ BTVAE_API int btvae_linear_wgrad(const float* dY, const float* X, int ldx, float
 }
 
 // Weight gradient of a Linear whose input is X = Y * scale + shift (column-wise, never materialised):
-// dW[N,K] (+)= scale[k] * (dY^T Y)[n,k] + shift[k] * dbias_cur[n], where dbias_cur[n] = sum_m dY[m,n].
+// dW[N,K] (+)= scale[k] * P[n,k] + shift[k] * dbias_cur[n], with P = dY^T Y and dbias_cur[n] = sum_m dY[m,n].
+// With W (this Linear's weight [N,K]) and col_wp / col_wb given, the same pass also leaves the two column reductions
+// the producing BatchNorm's backward needs in place of a pass over its activations:
+//   col_wp[k] (+)= sum_n W[n,k] P[n,k]  ( = sum_m G[m,k] Y[m,k] for G = dY W, the gradient reaching the BatchNorm output)
+//   col_wb[k] (+)= sum_n dbias_cur[n] W[n,k]  ( = sum_m G[m,k] ),   (+)= when cols_accumulate (a second consumer).
 BTVAE_API int btvae_linear_wgrad_affine(const float* dY, const float* Y, int ldy, const float* scale, const float* shift,
-                                        const float* dbias_cur, float* dW, float* ws, long long ws_floats,
+                                        const float* dbias_cur, const float* W, float* col_wp, float* col_wb, int cols_accumulate,
+                                        float* dW, float* ws, long long ws_floats,
                                         int M, int N, int K, int accumulate, void* stream) {
     BTVAE_REQUIRE(scale && shift && dbias_cur, "linear_wgrad_affine: null scale / shift / dbias_cur");
-    return matmul_tn_impl(dY, N, Y, ldy, dW, ws, ws_floats, N, K, M, accumulate, PK_GEMM_WGRAD, (hipStream_t)stream, scale, shift, dbias_cur);
+    BTVAE_REQUIRE((W != nullptr) == (col_wp != nullptr) && (W != nullptr) == (col_wb != nullptr), "linear_wgrad_affine: pass W, col_wp and col_wb together or none");
+    return matmul_tn_impl(dY, N, Y, ldy, dW, ws, ws_floats, N, K, M, accumulate, PK_GEMM_WGRAD, (hipStream_t)stream, scale, shift, dbias_cur,
+                          W, col_wp, col_wb, cols_accumulate);
 }
 
 // C[M,N] = A[M,K] B[N,K]^T + bias[N].

@@ -33,6 +33,18 @@ class Unit:
     dropout_p: float = 0.0
 
 
+class BwdProducts:
+    """Column reductions a BatchNorm's consumers leave while computing their weight gradients
+    (``btvae_linear_wgrad_affine``): ``wp[n] = sum_m G*Y``, ``wb[n] = sum_m G`` for the gradient G that reaches the
+    BatchNorm output.  Once every consumer has added its share, the BatchNorm backward needs no reduction pass."""
+
+    def __init__(self, n: int, device):
+        self.wp = torch.empty(n, device=device)
+        self.wb = torch.empty(n, device=device)
+        self.consumers = 0          # Linears that read the Normed in the forward
+        self.filled = 0             # of which have run their weight gradient
+
+
 @dataclass
 class Normed:
     """Output of a train-mode BatchNorm kept as its input plus the normalisation: ``y * scale + shift`` column-wise,
@@ -42,6 +54,7 @@ class Normed:
     invstd: torch.Tensor
     gamma: torch.Tensor
     beta: torch.Tensor
+    products: Optional["BwdProducts"] = None     # filled by the consumers' weight gradients in the backward
 
     @property
     def shape(self):
@@ -63,6 +76,8 @@ class Saved:
     total_rows: int = 0                      # rows the BatchNorm statistics span (> local rows under cross-rank sync)
     x_scale: Optional[torch.Tensor] = None   # Normed input: its column scale / shift (x = x_in * x_scale + x_shift)
     x_shift: Optional[torch.Tensor] = None
+    x_products: Optional[BwdProducts] = None # Normed input: where this unit's weight gradient leaves its by-products
+    out_products: Optional[BwdProducts] = None   # this unit returned a Normed: by-products its consumers fill
 
 
 class NetPlan:
@@ -153,12 +168,15 @@ def _check_train_supported(u: Unit, train: bool):
 
 
 FOLD_BN_INTO_CONSUMER = True     # train mode: leave BatchNorm outputs that only feed plain Linears unmaterialised
+BWD_SUMS_FROM_CONSUMERS = True   # ... and take their backward column sums from those Linears' weight gradients
 
 
 def _linear_operands(lin: torch.nn.Linear, x):
     """(A, W, b, scale, shift) of ``lin`` applied to ``x``: a tensor as is, a Normed input through folded weights."""
     if not isinstance(x, Normed):
         return x, lin.weight, lin.bias, None, None
+    if x.products is not None:
+        x.products.consumers += 1
     N, K = lin.weight.shape
     dev = x.device
     Wf, bf = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
@@ -178,6 +196,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
     _check_train_supported(u, train)
     if isinstance(x, Normed) and (u.residual or not train):
         raise RuntimeError("a residual unit needs its input materialised")
+    x_pr = x.products if isinstance(x, Normed) else None
     x, W, b, x_sc, x_sh = _linear_operands(u.lin, x)
     if u.bn is not None and train:
         if M * (BN_SYNC.world if BN_SYNC is not None else 1) <= 1:
@@ -204,10 +223,12 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         keep, ks = None, 1.0
         if u.dropout_p > 0.0:
             keep, ks = DROPOUT.keep(M, N, u.dropout_p, dev), 1.0 / (1.0 - u.dropout_p)
+        normed = keep_normed and FOLD_BN_INTO_CONSUMER and keep is None and not u.residual
+        out_pr = BwdProducts(N, dev) if (normed and saved is not None) else None
         if saved is not None:
-            saved.append(Saved(x, y, mean, invstd, keep, ks, total_rows, x_sc, x_sh))
-        if keep_normed and FOLD_BN_INTO_CONSUMER and keep is None and not u.residual:
-            return Normed(y, mean, invstd, u.bn.weight, u.bn.bias)
+            saved.append(Saved(x, y, mean, invstd, keep, ks, total_rows, x_sc, x_sh, x_pr, out_pr))
+        if normed:
+            return Normed(y, mean, invstd, u.bn.weight, u.bn.bias, out_pr)
         out = torch.empty(M, N, device=dev)
         nv.call("btvae_bn_apply_fwd", P(y), P(mean), P(invstd), P(u.bn.weight), P(u.bn.bias), P(x) if u.residual else None,
                 P(keep), ks, P(out), M, N)
@@ -224,7 +245,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         else:
             out = y
         if saved is not None:
-            saved.append(Saved(x, y, None, None, keep, ks, 0, x_sc, x_sh))
+            saved.append(Saved(x, y, None, None, keep, ks, 0, x_sc, x_sh, x_pr))
     else:
         out = torch.empty(M, N, device=dev)
         scale = shift = None
@@ -238,16 +259,17 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
 def head_forward(u: Unit, x, act: int, lo: float, hi: float, want_dfac: bool, want_sq: bool):
     """Head output Linear fused with its clamp / softplus / relu non-linearity
     (src/submodels.py:102-104,156-157).  ``x`` may be a ``Normed``.
-    Returns (value, dfac or None, value^2 or None, (scale, shift) of a Normed input or (None, None))."""
+    Returns (value, dfac or None, value^2 or None, (scale, shift, by-product holder) of a Normed input or Nones)."""
     M, K = x.shape
     N = u.lin.out_features
     dev = x.device
+    x_pr = x.products if isinstance(x, Normed) else None
     a, W, b, x_sc, x_sh = _linear_operands(u.lin, x)
     val = torch.empty(M, N, device=dev)
     dfac = torch.empty(M, N, device=dev) if want_dfac else None
     sq = torch.empty(M, N, device=dev) if want_sq else None
     nv.call("btvae_linear_head_fwd", P(a), K, P(W), P(b), act, float(lo), float(hi), P(val), P(dfac), P(sq), M, K, N)
-    return val, dfac, sq, (x_sc, x_sh)
+    return val, dfac, sq, (x_sc, x_sh, x_pr)
 
 
 @dataclass
@@ -299,16 +321,22 @@ def _grad_view(p: torch.nn.Parameter) -> torch.Tensor:
     return p.grad
 
 
-def _wgrad(lin: torch.nn.Linear, dy: torch.Tensor, x: torch.Tensor, x_scale, x_shift, db_cur, accumulate: bool):
-    """lin.weight.grad (+)= dy^T x', x' = x (plain input) or x * x_scale + x_shift (the input was a Normed)."""
+def _wgrad(lin: torch.nn.Linear, dy: torch.Tensor, x: torch.Tensor, x_scale, x_shift, db_cur, accumulate: bool,
+           products: Optional[BwdProducts] = None):
+    """lin.weight.grad (+)= dy^T x', x' = x (plain input) or x * x_scale + x_shift (the input was a Normed; its
+    producer's backward by-products are added to ``products``)."""
     M, N = dy.shape
     K = x.shape[1]
     ws = WS.get("wgrad", WGRAD_WS_FLOATS, dy.device)
     if x_scale is None:
         nv.call("btvae_linear_wgrad", P(dy), P(x), K, P(_grad_view(lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
+    elif products is not None and BWD_SUMS_FROM_CONSUMERS:
+        nv.call("btvae_linear_wgrad_affine", P(dy), P(x), K, P(x_scale), P(x_shift), P(db_cur), P(lin.weight), P(products.wp), P(products.wb),
+                int(products.filled > 0), P(_grad_view(lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
+        products.filled += 1
     else:
-        nv.call("btvae_linear_wgrad_affine", P(dy), P(x), K, P(x_scale), P(x_shift), P(db_cur), P(_grad_view(lin.weight)), P(ws), ws.numel(),
-                M, N, K, int(accumulate))
+        nv.call("btvae_linear_wgrad_affine", P(dy), P(x), K, P(x_scale), P(x_shift), P(db_cur), None, None, None, 0,
+                P(_grad_view(lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
 
 
 def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.Tensor], need_dx: bool, accumulate: bool):
@@ -319,8 +347,19 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
     scr = WS.get("bnbwd", nv.lib().btvae_bn_relu_bwd_scratch(M, N), dev)
     dpre = torch.empty(M, N, device=dev)
     db_cur = torch.empty(N, device=dev) if sv.x_scale is not None else None    # this pass's bias gradient, for the affine wgrad
+    pr = sv.out_products
     if u.bn is None:
         nv.call("btvae_relu_bwd", P(g), P(sv.y), P(sv.keep), float(sv.keep_scale), P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
+    elif pr is not None and pr.consumers > 0 and pr.filled == pr.consumers and sv.keep is None:
+        # every reader of this unit's output was a folded Linear whose weight gradient has run: the column sums of
+        # G and G*xhat follow from their by-products, no reduction pass over G and Y
+        sums = torch.empty(2, N, device=dev)
+        nv.call("btvae_bn_bwd_sums_from_products", P(pr.wp), P(pr.wb), P(sv.mean), P(sv.invstd),
+                P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)), P(sums), N, int(accumulate))
+        if sv.total_rows > M:
+            BN_SYNC.sum_(sums)
+        nv.call("btvae_bn_relu_bwd_apply", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), None, 1.0,
+                P(sums), int(max(sv.total_rows, M)), P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
     elif sv.total_rows > M:
         # statistics span ranks: local column sums -> sum over ranks -> dPre with the batch-wide sums
         sums = torch.empty(2, N, device=dev)
@@ -333,7 +372,7 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
         nv.call("btvae_bn_relu_bwd", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
                 P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)),
                 P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
-    _wgrad(u.lin, dpre, sv.x_in, sv.x_scale, sv.x_shift, db_cur, accumulate)
+    _wgrad(u.lin, dpre, sv.x_in, sv.x_scale, sv.x_shift, db_cur, accumulate, sv.x_products)
     if not need_dx:
         return None
     r = None
@@ -362,10 +401,10 @@ def net_backward(plan: NetPlan, tape: NetTape, draw: Dict[str, torch.Tensor], ne
         t_in = tape.head_in[name]
         K = t_in.shape[1]
         cs = WS.get("colsum", nv.lib().btvae_strip_chunks(M) * N, dev)
-        x_sc, x_sh = tape.head_in_affine.get(name, (None, None))
+        x_sc, x_sh, x_pr = tape.head_in_affine.get(name, (None, None, None))
         db_cur = torch.empty(N, device=dev) if x_sc is not None else None
         nv.call("btvae_colsum", P(d), P(_grad_view(last.lin.bias)), P(db_cur), P(cs), M, N, int(accumulate))
-        _wgrad(last.lin, d, t_in, x_sc, x_sh, db_cur, accumulate)
+        _wgrad(last.lin, d, t_in, x_sc, x_sh, db_cur, accumulate, x_pr)
         g = torch.empty(M, K, device=dev)
         nv.call("btvae_linear_dgrad", P(d), P(last.lin.weight), None, P(g), K, M, N, K)
         svs = tape.heads[name]

@@ -122,8 +122,14 @@ int btvae_colsum(const float* G, float* out, float* cur, float* scratch, int M, 
 int btvae_bn_fold_linear(const float* W, const float* b, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, float* Wf, float* bf, float* scale, float* shift, int N, int K, void* stream);
 int btvae_linear_wgrad_affine(const float* dY, const float* Y, int ldy, const float* scale, const float* shift,
-                              const float* dbias_cur, float* dW, float* ws, long long ws_floats,
-                              int M, int N, int K, int accumulate, void* stream);
+                              const float* dbias_cur, const float* W, float* col_wp, float* col_wb, int cols_accumulate,
+                              float* dW, float* ws, long long ws_floats, int M, int N, int K, int accumulate, void* stream);
+/* With W, col_wp, col_wb given, btvae_linear_wgrad_affine also leaves col_wp[k] (+)= sum_n W[n,k] (dY^T Y)[n,k] and
+ * col_wb[k] (+)= sum_n dbias_cur[n] W[n,k]: the sums over rows of G*Y and G for G = dY W, the gradient that reaches
+ * the BatchNorm output (src/submodels.py:19-21 backward).  From them the BatchNorm-backward column sums follow without
+ * a pass over the activations: sums[0] = col_wb, sums[1] = invstd (col_wp - mean col_wb); then btvae_bn_relu_bwd_apply. */
+int btvae_bn_bwd_sums_from_products(const float* col_wp, const float* col_wb, const float* mean, const float* invstd,
+                                    float* dgamma, float* dbeta, float* sums, int N, int accumulate, void* stream);
 
 /* ---- reparameterisation, KL, likelihoods ---- */
 /* z = mu + sigma*eps (src/submodels.py:108-109) written next to the broadcast condition as decoder input rows

@@ -135,15 +135,28 @@ def test_bn_fold_linear_and_affine_wgrad(dev, gemm_mode, M, N, K):
     out = torch.empty(M, N, device=dev)
     nv.call("btvae_matmul_nt_bias", P(d["Y"]), K, P(Wf), K, P(bf), P(out), N, M, N, K)
     close(out, ref_out, 1e-4, 2e-5 * math.sqrt(K), "folded forward")
-    ws = torch.empty(4 * 1024 * 1024, device=dev)
+    ws = torch.empty(8 * 1024 * 1024, device=dev)
     cs = torch.empty(nv.lib().btvae_strip_chunks(M) * N, device=dev)
     dbc = torch.empty(N, device=dev)
     nv.call("btvae_colsum", P(d["dY"]), None, P(dbc), P(cs), M, N, 0)
     dW = torch.full((N, K), 0.5, device=dev)
-    nv.call("btvae_linear_wgrad_affine", P(d["dY"]), P(d["Y"]), K, P(scd), P(shd), P(dbc), P(dW), P(ws), ws.numel(), M, N, K, 1)
+    nv.call("btvae_linear_wgrad_affine", P(d["dY"]), P(d["Y"]), K, P(scd), P(shd), P(dbc), None, None, None, 0, P(dW), P(ws), ws.numel(), M, N, K, 1)
     close(dW, 0.5 + ref_dW, 1e-4, 2e-5 * math.sqrt(M), "affine wgrad (accumulate)")
-    nv.call("btvae_linear_wgrad_affine", P(d["dY"]), P(d["Y"]), K, P(scd), P(shd), P(dbc), P(dW), P(ws), ws.numel(), M, N, K, 0)
+    # with the column by-products: sum_m G*Y and sum_m G for G = dY W, and from them the BatchNorm-backward sums
+    cwp, cwb = torch.full((K,), 0.25, device=dev), torch.full((K,), -0.5, device=dev)
+    nv.call("btvae_linear_wgrad_affine", P(d["dY"]), P(d["Y"]), K, P(scd), P(shd), P(dbc), P(d["W"]), P(cwp), P(cwb), 1, P(dW), P(ws), ws.numel(), M, N, K, 0)
     close(dW, ref_dW, 1e-4, 2e-5 * math.sqrt(M), "affine wgrad")
+    G = dY @ W
+    s = math.sqrt(M * N)
+    close(cwp, 0.25 + (G * Y).sum(0), 1e-4, 1e-5 * s, "sum G*Y")
+    close(cwb, -0.5 + G.sum(0), 1e-4, 1e-5 * s, "sum G")
+    nv.call("btvae_linear_wgrad_affine", P(d["dY"]), P(d["Y"]), K, P(scd), P(shd), P(dbc), P(d["W"]), P(cwp), P(cwb), 0, P(dW), P(ws), ws.numel(), M, N, K, 0)
+    sums, dgam, dbet = torch.empty(2, K, device=dev), torch.zeros(K, device=dev), torch.zeros(K, device=dev)
+    nv.call("btvae_bn_bwd_sums_from_products", P(cwp), P(cwb), P(d["mean"]), P(d["inv"]), P(dgam), P(dbet), P(sums), K, 0)
+    xhat = (Y - mean) * inv
+    close(sums[0], G.sum(0), 1e-4, 1e-5 * s, "dbeta from products")
+    close(sums[1], (G * xhat).sum(0), 1e-4, 2e-5 * s, "dgamma from products")
+    assert torch.equal(dgam, sums[1]) and torch.equal(dbet, sums[0])
 
 
 def test_matmul_bias_and_mul(dev):
