@@ -598,6 +598,14 @@ BTVAE_API int btvae_relu_bwd(const float* G, const float* Y, const unsigned char
     return check_launch("relu_bwd");
 }
 
+// out[N] (+)= sum over nchunks of partials[chunk][N], cur[N] = the sum alone (either may be null): finishes column sums
+// that another kernel left per row tile (btvae_linear_dgrad_bnbwd).
+BTVAE_API int btvae_colsum_partials(const float* partials, int nchunks, int N, float* out, float* cur, int accumulate, void* stream) {
+    BTVAE_REQUIRE(partials && (out || cur) && nchunks > 0 && N > 0, "colsum_partials: bad argument");
+    colsum_finalize((hipStream_t)stream, partials, nchunks, 1, N, out, (float*)nullptr, cur, (float*)nullptr, accumulate);
+    return check_launch("colsum_partials");
+}
+
 // Scratch floats btvae_bn_relu_bwd needs for an [M,N] activation.
 BTVAE_API long long btvae_bn_relu_bwd_scratch(int M, int N) { return (long long)3 * chunk_count(M) * N + 2LL * N; }
 

@@ -457,6 +457,25 @@ BTVAE_API int btvae_linear_dgrad(const float* dY, const float* W, const float* R
     return launch<LAY_K, LAY_M, EPI_PLAIN>(a, 1, (hipStream_t)stream, "linear_dgrad", true);
 }
 
+// dX-side product fused with the BatchNorm+ReLU backward of the unit whose output X = BN(relu(.)) the Linear read:
+// G[M,K] = dY[M,N] W[N,K] (+ R) is the gradient reaching that BatchNorm output; written instead is
+// dPre[M,K] = (Yb > 0) * gamma*invstd * (G - sums[0]/rows - xhat*sums[1]/rows), xhat = (Yb - mean)*invstd, and
+// colpart[ceil(M/128)][K] = per-row-tile column sums of dPre (the bias gradient after btvae_colsum_partials).
+// sums[2][K] must be final before the call (btvae_bn_bwd_sums_from_products).  K % 4 == 0 and 16-byte aligned tensors.
+BTVAE_API int btvae_linear_dgrad_bnbwd(const float* dY, const float* W, const float* R, const float* Yb, const float* mean,
+                                       const float* invstd, const float* gamma, const float* sums, long long total_rows,
+                                       float* dPre, float* colpart, int M, int N, int K, void* stream) {
+    BTVAE_REQUIRE(Yb && mean && invstd && gamma && sums && dPre && colpart, "linear_dgrad_bnbwd: null pointer");
+    BTVAE_REQUIRE(total_rows >= M, "linear_dgrad_bnbwd: total_rows %lld < local rows %d", total_rows, M);
+    BTVAE_REQUIRE(K % 4 == 0 && aligned16(dPre) && aligned16(Yb) && (!R || aligned16(R)), "linear_dgrad_bnbwd: needs K %% 4 == 0 and 16-byte aligned tensors");
+    GemmArgs a{}; a.A = dY; a.lda = N; a.B = W; a.ldb = K; a.C = dPre; a.ldc = K; a.M = M; a.N = K; a.K = N;
+    a.R = R; a.ldr = K;
+    a.bn_y = Yb; a.bn_mean = mean; a.bn_invstd = invstd; a.bn_gamma = gamma; a.bn_sums = sums; a.bn_inv_rows = 1.f / (float)total_rows;
+    a.colpart = colpart;
+    ProfScope ps(PK_GEMM_DGRAD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * N + (double)N * K + 2.0 * M * K));
+    return launch<LAY_K, LAY_M, EPI_BNBWD>(a, 1, (hipStream_t)stream, "linear_dgrad_bnbwd", true);
+}
+
 // C[M,N] (+)= A^T B with A stored [K][M] (lda) and B stored [K][N] (ldb); the reduction is split over
 // workgroups into slabs held in `ws` and summed by a second kernel.  accumulate != 0 adds to C.
 static int matmul_tn_impl(const float* A, int lda, const float* B, int ldb, float* C, float* ws, long long ws_floats,

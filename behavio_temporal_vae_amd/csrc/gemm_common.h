@@ -11,7 +11,7 @@ namespace btvae_gemm {
 constexpr int BM = 128, BN = 128;
 
 enum { LAY_K = 0, LAY_M = 1 };
-enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_RELU_STATS = 2, EPI_RELU_AFFINE = 3, EPI_HEAD = 4, EPI_MUL = 5 };
+enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_RELU_STATS = 2, EPI_RELU_AFFINE = 3, EPI_HEAD = 4, EPI_MUL = 5, EPI_BNBWD = 6 };
 
 struct GemmArgs {
     const float* A; const float* B; float* C;
@@ -26,6 +26,13 @@ struct GemmArgs {
     float* stats;               // EPI_RELU_STATS: [tiles_m][2][N] = per-tile column (mean, M2)
     const float* E1; const float* E2; int lde;  // EPI_MUL
     int act; float lo, hi;      // EPI_HEAD
+    // EPI_BNBWD: the product (+R) is the gradient G reaching a BatchNorm output; the epilogue writes
+    // dPre = (Y > 0) * gamma*invstd * (G - dbeta/rows - xhat*dgamma/rows) and per-row-tile column sums of dPre
+    const float* bn_y;          // [M, N] post-ReLU pre-BatchNorm activations (row pitch ldc)
+    const float* bn_mean; const float* bn_invstd; const float* bn_gamma;   // [N]
+    const float* bn_sums;       // [2][N]: sum G, sum G*xhat over the rows the statistics span
+    float bn_inv_rows;
+    float* colpart;             // [tiles_m][N]
     int a_vec, b_vec;
     int c_vec;                  // outputs / add-ins allow 16-byte row accesses: epilogue staged through LDS
     int tiles_m, tiles_n;
@@ -208,6 +215,21 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
     // column statistics (EPI_RELU_STATS): shifted sums per lane over its rows of both halves
     float st_k[2] = {0.f, 0.f}, st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f}, st_c[2] = {0.f, 0.f};
     bool have[2] = {false, false};
+    // EPI_BNBWD: constants of this thread's four output columns (the same in both halves), running column sums of dPre
+    float bmu[4], bis[4], bk0[4], bk1[4], bk2[4], bsb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_BNBWD) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = n0 + ((tid & 31) << 2) + e;
+            const bool ok = c < p.N;
+            bmu[e] = ok ? p.bn_mean[c] : 0.f;
+            bis[e] = ok ? p.bn_invstd[c] : 0.f;
+            const float gi = ok ? p.bn_gamma[c] * bis[e] : 0.f;
+            bk0[e] = gi;
+            bk1[e] = ok ? gi * p.bn_sums[c] * p.bn_inv_rows : 0.f;
+            bk2[e] = ok ? gi * p.bn_sums[p.N + c] * p.bn_inv_rows : 0.f;
+        }
+    }
 
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
@@ -249,6 +271,16 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
                     st4(Cz + o, v);
                 } else if (EPI == EPI_RELU_STATS) {
                     st4(Cz + o, v);
+                } else if (EPI == EPI_BNBWD) {
+                    if (p.R) { const float4 q = ld4(p.R + (size_t)row * p.ldr + col); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+                    const float4 y = ld4(p.bn_y + o);
+                    float4 d;
+                    d.x = y.x > 0.f ? bk0[0] * v.x - bk1[0] - bk2[0] * ((y.x - bmu[0]) * bis[0]) : 0.f;
+                    d.y = y.y > 0.f ? bk0[1] * v.y - bk1[1] - bk2[1] * ((y.y - bmu[1]) * bis[1]) : 0.f;
+                    d.z = y.z > 0.f ? bk0[2] * v.z - bk1[2] - bk2[2] * ((y.z - bmu[2]) * bis[2]) : 0.f;
+                    d.w = y.w > 0.f ? bk0[3] * v.w - bk1[3] - bk2[3] * ((y.w - bmu[3]) * bis[3]) : 0.f;
+                    st4(Cz + o, d);
+                    bsb[0] += d.x; bsb[1] += d.y; bsb[2] += d.z; bsb[3] += d.w;
                 } else if (EPI == EPI_MUL) {
                     const size_t e = (size_t)row * p.lde + col;
                     const float4 a = ld4(p.E1 + e), b = ld4(p.E2 + e);
@@ -278,6 +310,20 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             }
         }
         __syncthreads();
+    }
+
+    if (EPI == EPI_BNBWD) {
+        // column sums of dPre over this tile's rows: 8 row groups (tid >> 5) per column quad -> LDS -> one thread per column
+        float* cs = lds;                              // the image is free: the last half's barrier has passed
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cs[(tid >> 5) * 128 + ((tid & 31) << 2) + e] = bsb[e];
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += cs[q * 128 + tid];
+            p.colpart[(size_t)tile_m * p.N + n0 + tid] = t;
+        }
     }
 
     if (EPI == EPI_RELU_STATS) {

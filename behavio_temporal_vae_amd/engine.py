@@ -43,6 +43,9 @@ class BwdProducts:
         self.wb = torch.empty(n, device=device)
         self.consumers = 0          # Linears that read the Normed in the forward
         self.filled = 0             # of which have run their weight gradient
+        self.owner = None           # (Unit, Saved) of the BatchNorm unit
+        self.dpre = None            # set once the last consumer's dX product has run that unit's BatchNorm backward
+        self.db_cur = None
 
 
 @dataclass
@@ -169,6 +172,7 @@ def _check_train_supported(u: Unit, train: bool):
 
 FOLD_BN_INTO_CONSUMER = True     # train mode: leave BatchNorm outputs that only feed plain Linears unmaterialised
 BWD_SUMS_FROM_CONSUMERS = True   # ... and take their backward column sums from those Linears' weight gradients
+BWD_FUSED_INTO_CONSUMER = not __import__('os').environ.get('BTVAE_NO_FUSED_BWD')   # ... and run their BatchNorm backward in the epilogue of the last such Linear's dX product
 
 
 def _linear_operands(lin: torch.nn.Linear, x):
@@ -227,6 +231,8 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         out_pr = BwdProducts(N, dev) if (normed and saved is not None) else None
         if saved is not None:
             saved.append(Saved(x, y, mean, invstd, keep, ks, total_rows, x_sc, x_sh, x_pr, out_pr))
+            if out_pr is not None:
+                out_pr.owner = (u, saved[-1])
         if normed:
             return Normed(y, mean, invstd, u.bn.weight, u.bn.bias, out_pr)
         out = torch.empty(M, N, device=dev)
@@ -339,16 +345,57 @@ def _wgrad(lin: torch.nn.Linear, dy: torch.Tensor, x: torch.Tensor, x_scale, x_s
                 P(_grad_view(lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
 
 
+def _fusable(pr: Optional[BwdProducts]) -> bool:
+    """The producing BatchNorm's backward can run inside this (last) consumer's dX product: every consumer's weight
+    gradient has left its by-products, and the fused kernel's alignment need holds."""
+    if pr is None or not (BWD_SUMS_FROM_CONSUMERS and BWD_FUSED_INTO_CONSUMER) or pr.owner is None:
+        return False
+    _, sv_p = pr.owner
+    return pr.consumers > 0 and pr.filled == pr.consumers and sv_p.keep is None and sv_p.y.shape[1] % 4 == 0
+
+
+def _dgrad_with_producer_backward(pr: BwdProducts, dy: torch.Tensor, W: torch.Tensor, r: Optional[torch.Tensor], accumulate: bool):
+    """dX product of a Linear that read a Normed, fused with the BatchNorm+ReLU backward of the unit that produced it.
+    Returns that unit's dPre (what its own backward continues from); its BatchNorm and bias gradients are written."""
+    u_p, sv_p = pr.owner
+    M, N = dy.shape
+    Np = sv_p.y.shape[1]
+    dev = dy.device
+    sums = torch.empty(2, Np, device=dev)
+    nv.call("btvae_bn_bwd_sums_from_products", P(pr.wp), P(pr.wb), P(sv_p.mean), P(sv_p.invstd),
+            P(_grad_view(u_p.bn.weight)), P(_grad_view(u_p.bn.bias)), P(sums), Np, int(accumulate))
+    if sv_p.total_rows > M:
+        BN_SYNC.sum_(sums)
+    tiles = (M + 127) // 128
+    dpre = torch.empty(M, Np, device=dev)
+    part = WS.get("bnbwd_part", tiles * Np, dev)
+    nv.call("btvae_linear_dgrad_bnbwd", P(dy), P(W), P(r), P(sv_p.y), P(sv_p.mean), P(sv_p.invstd), P(u_p.bn.weight), P(sums),
+            int(max(sv_p.total_rows, M)), P(dpre), P(part), M, N, Np)
+    db_cur = torch.empty(Np, device=dev) if sv_p.x_scale is not None else None
+    nv.call("btvae_colsum_partials", P(part), tiles, Np, P(_grad_view(u_p.lin.bias)), P(db_cur), int(accumulate))
+    pr.dpre, pr.db_cur = dpre, db_cur
+    return dpre
+
+
 def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.Tensor], need_dx: bool, accumulate: bool):
     """Backward of a ReLU+BN unit.  g = dL/d(out).  Returns dL/d(x_in) (+ add_to, + g for residual units)."""
     M, N = g.shape
     K = sv.x_in.shape[1]
     dev = g.device
-    scr = WS.get("bnbwd", nv.lib().btvae_bn_relu_bwd_scratch(M, N), dev)
-    dpre = torch.empty(M, N, device=dev)
-    db_cur = torch.empty(N, device=dev) if sv.x_scale is not None else None    # this pass's bias gradient, for the affine wgrad
     pr = sv.out_products
-    if u.bn is None:
+    fused_done = pr is not None and pr.dpre is not None
+    if fused_done:
+        # the last consumer's dX product already ran this unit's BatchNorm backward: g is this unit's dPre
+        if g is not pr.dpre:
+            raise RuntimeError("fused BatchNorm backward: the gradient handed on is not the one the consumer produced")
+        dpre, db_cur, scr = pr.dpre, pr.db_cur, None
+    else:
+        scr = WS.get("bnbwd", nv.lib().btvae_bn_relu_bwd_scratch(M, N), dev)
+        dpre = torch.empty(M, N, device=dev)
+        db_cur = torch.empty(N, device=dev) if sv.x_scale is not None else None    # this pass's bias gradient, for the affine wgrad
+    if fused_done:
+        pass
+    elif u.bn is None:
         nv.call("btvae_relu_bwd", P(g), P(sv.y), P(sv.keep), float(sv.keep_scale), P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
     elif pr is not None and pr.consumers > 0 and pr.filled == pr.consumers and sv.keep is None:
         # every reader of this unit's output was a folded Linear whose weight gradient has run: the column sums of
@@ -382,6 +429,8 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
         r = g
     elif add_to is not None:
         r = add_to
+    if _fusable(sv.x_products):
+        return _dgrad_with_producer_backward(sv.x_products, dpre, u.lin.weight, r, accumulate)
     dx = torch.empty(M, K, device=dev)
     nv.call("btvae_linear_dgrad", P(dpre), P(u.lin.weight), P(r), P(dx), K, M, N, K)
     return dx
@@ -405,8 +454,11 @@ def net_backward(plan: NetPlan, tape: NetTape, draw: Dict[str, torch.Tensor], ne
         db_cur = torch.empty(N, device=dev) if x_sc is not None else None
         nv.call("btvae_colsum", P(d), P(_grad_view(last.lin.bias)), P(db_cur), P(cs), M, N, int(accumulate))
         _wgrad(last.lin, d, t_in, x_sc, x_sh, db_cur, accumulate, x_pr)
-        g = torch.empty(M, K, device=dev)
-        nv.call("btvae_linear_dgrad", P(d), P(last.lin.weight), None, P(g), K, M, N, K)
+        if _fusable(x_pr):
+            g = _dgrad_with_producer_backward(x_pr, d, last.lin.weight, None, accumulate)
+        else:
+            g = torch.empty(M, K, device=dev)
+            nv.call("btvae_linear_dgrad", P(d), P(last.lin.weight), None, P(g), K, M, N, K)
         svs = tape.heads[name]
         for i in range(len(units) - 2, -1, -1):
             first = i == 0

@@ -128,6 +128,14 @@ int btvae_linear_wgrad_affine(const float* dY, const float* Y, int ldy, const fl
  * col_wb[k] (+)= sum_n dbias_cur[n] W[n,k]: the sums over rows of G*Y and G for G = dY W, the gradient that reaches
  * the BatchNorm output (src/submodels.py:19-21 backward).  From them the BatchNorm-backward column sums follow without
  * a pass over the activations: sums[0] = col_wb, sums[1] = invstd (col_wp - mean col_wb); then btvae_bn_relu_bwd_apply. */
+/* The consumer's dX product fused with that BatchNorm's backward: dPre of the producing unit is written where the gradient
+ * G = dY W (+R) would have been, plus per-128-row-tile column sums of dPre (colpart[ceil(M/128)][K], finished into the bias
+ * gradient by btvae_colsum_partials).  sums[2][K] from btvae_bn_bwd_sums_from_products (all-reduced when statistics span
+ * ranks; total_rows = rows they span).  Needs K % 4 == 0. */
+int btvae_linear_dgrad_bnbwd(const float* dY, const float* W, const float* R, const float* Yb, const float* mean,
+                             const float* invstd, const float* gamma, const float* sums, long long total_rows,
+                             float* dPre, float* colpart, int M, int N, int K, void* stream);
+int btvae_colsum_partials(const float* partials, int nchunks, int N, float* out, float* cur, int accumulate, void* stream);
 int btvae_bn_bwd_sums_from_products(const float* col_wp, const float* col_wb, const float* mean, const float* invstd,
                                     float* dgamma, float* dbeta, float* sums, int N, int accumulate, void* stream);
 

@@ -159,6 +159,33 @@ def test_bn_fold_linear_and_affine_wgrad(dev, gemm_mode, M, N, K):
     assert torch.equal(dgam, sums[1]) and torch.equal(dbet, sums[0])
 
 
+@pytest.mark.parametrize("M,N,K,with_r", [(300, 100, 1000, True), (130, 48, 72, False), (1000, 1000, 1000, True)])
+def test_dgrad_fused_with_batchnorm_backward(dev, gemm_mode, M, N, K, with_r):
+    """dX product fused with the producing unit's BatchNorm+ReLU backward against fp64: dPre and its column sums,
+    for column sums (sum G, sum G*xhat) taken from G itself."""
+    dY = rnd(M, N, seed=21); W = rnd(N, K, seed=22) * 0.1
+    R = rnd(M, K, seed=23) if with_r else None
+    Yb = torch.relu(rnd(M, K, seed=24) + 0.2)
+    gam = 1 + 0.3 * rnd(K, seed=25)
+    mean = Yb.mean(0); inv = 1 / torch.sqrt(Yb.var(0, unbiased=False) + 1e-5)
+    G = dY @ W + (R if with_r else 0)
+    xhat = (Yb - mean) * inv
+    s0, s1 = G.sum(0), (G * xhat).sum(0)
+    ref = torch.where(Yb > 0, gam * inv * (G - s0 / M - xhat * s1 / M), torch.zeros_like(G))
+    f = lambda t: None if t is None else t.float().to(dev).contiguous()
+    d = {k: f(v) for k, v in dict(dY=dY, W=W, R=R, Yb=Yb, gam=gam, mean=mean, inv=inv, sums=torch.stack([s0, s1])).items()}
+    tiles = (M + 127) // 128
+    dpre, part = torch.empty(M, K, device=dev), torch.empty(tiles, K, device=dev)
+    nv.call("btvae_linear_dgrad_bnbwd", P(d["dY"]), P(d["W"]), P(d["R"]), P(d["Yb"]), P(d["mean"]), P(d["inv"]), P(d["gam"]), P(d["sums"]), M,
+            P(dpre), P(part), M, N, K)
+    scale = float((gam * inv).abs().max())
+    close(dpre, ref, 1e-4, scale * (2e-6 * math.sqrt(N) + 1e-6 * math.sqrt(M)), "fused dPre")
+    db, cur = torch.ones(K, device=dev), torch.empty(K, device=dev)
+    nv.call("btvae_colsum_partials", P(part), tiles, K, P(db), P(cur), 1)
+    close(cur, ref.sum(0), 1e-4, scale * 1e-5 * math.sqrt(M) * math.sqrt(N), "dbias")
+    close(db, 1 + ref.sum(0), 1e-4, scale * 1e-5 * math.sqrt(M) * math.sqrt(N), "dbias accumulated")
+
+
 def test_matmul_bias_and_mul(dev):
     M, K, N = 260, 100, 1176
     A, B, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
