@@ -45,6 +45,8 @@ _SIGS = {
     "btvae_bn_bwd_sums_from_products": [P, P, P, P, P, P, P, I, I, P],
     "btvae_linear_dgrad_bnbwd": [P, P, P, P, P, P, P, P, LL, P, P, I, I, I, P],
     "btvae_colsum_partials": [P, I, I, P, P, I, P],
+    "btvae_linear_dgrad_gstats": [P, P, P, P, P, P, P, P, I, I, I, P],
+    "btvae_bn_bwd_sums_from_partials": [P, I, I, P, P, P, I, P],
     "btvae_bn_stats_local": [P, I, I, I, P, P],
     "btvae_bn_stats_merge": [P, I, I, I, P, P, P, P, F, F, P],
     "btvae_bn_relu_bwd_sums": [P, P, P, P, P, F, P, P, P, P, I, I, I, P],

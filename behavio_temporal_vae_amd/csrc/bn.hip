@@ -606,6 +606,15 @@ BTVAE_API int btvae_colsum_partials(const float* partials, int nchunks, int N, f
     return check_launch("colsum_partials");
 }
 
+// First half of the BatchNorm backward from per-row-tile partials another kernel left (btvae_linear_dgrad_gstats):
+// partials[nchunks][2][N] -> sums[0] = sum g, sums[1] = sum g*xhat, added into dbeta / dgamma like btvae_bn_relu_bwd_sums.
+BTVAE_API int btvae_bn_bwd_sums_from_partials(const float* partials, int nchunks, int N, float* dgamma, float* dbeta, float* sums,
+                                              int accumulate, void* stream) {
+    BTVAE_REQUIRE(partials && dgamma && dbeta && sums && nchunks > 0 && N > 0, "bn_bwd_sums_from_partials: bad argument");
+    colsum_finalize((hipStream_t)stream, partials, nchunks, 2, N, dbeta, dgamma, sums, sums + N, accumulate);
+    return check_launch("bn_bwd_sums_from_partials");
+}
+
 // Scratch floats btvae_bn_relu_bwd needs for an [M,N] activation.
 BTVAE_API long long btvae_bn_relu_bwd_scratch(int M, int N) { return (long long)3 * chunk_count(M) * N + 2LL * N; }
 

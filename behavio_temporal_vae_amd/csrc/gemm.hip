@@ -476,6 +476,20 @@ BTVAE_API int btvae_linear_dgrad_bnbwd(const float* dY, const float* W, const fl
     return launch<LAY_K, LAY_M, EPI_BNBWD>(a, 1, (hipStream_t)stream, "linear_dgrad_bnbwd", true);
 }
 
+// dX[M,K] = dY[M,N] W[N,K] (+ R) = the gradient G reaching a BatchNorm output, plus the reduction pass of that
+// BatchNorm's backward from the same epilogue: gpart[ceil(M/128)][2][K] = per-row-tile column sums of G and G*xhat,
+// xhat = (Yb - mean) * invstd (finished by btvae_bn_bwd_sums_from_partials).  K % 4 == 0, 16-byte aligned tensors.
+BTVAE_API int btvae_linear_dgrad_gstats(const float* dY, const float* W, const float* R, const float* Yb, const float* mean,
+                                        const float* invstd, float* dX, float* gpart, int M, int N, int K, void* stream) {
+    BTVAE_REQUIRE(Yb && mean && invstd && dX && gpart, "linear_dgrad_gstats: null pointer");
+    BTVAE_REQUIRE(K % 4 == 0 && aligned16(dX) && aligned16(Yb) && (!R || aligned16(R)), "linear_dgrad_gstats: needs K %% 4 == 0 and 16-byte aligned tensors");
+    GemmArgs a{}; a.A = dY; a.lda = N; a.B = W; a.ldb = K; a.C = dX; a.ldc = K; a.M = M; a.N = K; a.K = N;
+    a.R = R; a.ldr = K;
+    a.bn_y = Yb; a.bn_mean = mean; a.bn_invstd = invstd; a.gpart = gpart;
+    ProfScope ps(PK_GEMM_DGRAD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * N + (double)N * K + 2.0 * M * K));
+    return launch<LAY_K, LAY_M, EPI_GSTATS>(a, 1, (hipStream_t)stream, "linear_dgrad_gstats", true);
+}
+
 // C[M,N] (+)= A^T B with A stored [K][M] (lda) and B stored [K][N] (ldb); the reduction is split over
 // workgroups into slabs held in `ws` and summed by a second kernel.  accumulate != 0 adds to C.
 static int matmul_tn_impl(const float* A, int lda, const float* B, int ldb, float* C, float* ws, long long ws_floats,

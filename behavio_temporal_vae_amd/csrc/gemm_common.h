@@ -11,7 +11,7 @@ namespace btvae_gemm {
 constexpr int BM = 128, BN = 128;
 
 enum { LAY_K = 0, LAY_M = 1 };
-enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_RELU_STATS = 2, EPI_RELU_AFFINE = 3, EPI_HEAD = 4, EPI_MUL = 5, EPI_BNBWD = 6 };
+enum { EPI_PLAIN = 0, EPI_BIAS = 1, EPI_RELU_STATS = 2, EPI_RELU_AFFINE = 3, EPI_HEAD = 4, EPI_MUL = 5, EPI_BNBWD = 6, EPI_GSTATS = 7 };
 
 struct GemmArgs {
     const float* A; const float* B; float* C;
@@ -33,6 +33,9 @@ struct GemmArgs {
     const float* bn_sums;       // [2][N]: sum G, sum G*xhat over the rows the statistics span
     float bn_inv_rows;
     float* colpart;             // [tiles_m][N]
+    // EPI_GSTATS: the product (+R) = G is written as is; gpart[tiles_m][2][N] = per-row-tile column sums of G and of
+    // G*xhat, xhat = (bn_y - bn_mean) * bn_invstd (the reduction pass of that BatchNorm's backward)
+    float* gpart;
     int a_vec, b_vec;
     int c_vec;                  // outputs / add-ins allow 16-byte row accesses: epilogue staged through LDS
     int tiles_m, tiles_n;
@@ -217,6 +220,16 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
     bool have[2] = {false, false};
     // EPI_BNBWD: constants of this thread's four output columns (the same in both halves), running column sums of dPre
     float bmu[4], bis[4], bk0[4], bk1[4], bk2[4], bsb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_GSTATS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = n0 + ((tid & 31) << 2) + e;
+            const bool ok = c < p.N;
+            bmu[e] = ok ? p.bn_mean[c] : 0.f;
+            bis[e] = ok ? p.bn_invstd[c] : 0.f;
+            bk0[e] = 0.f;                              // running sum of G*xhat
+        }
+    }
     if (EPI == EPI_BNBWD) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -271,6 +284,13 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
                     st4(Cz + o, v);
                 } else if (EPI == EPI_RELU_STATS) {
                     st4(Cz + o, v);
+                } else if (EPI == EPI_GSTATS) {
+                    if (p.R) { const float4 q = ld4(p.R + (size_t)row * p.ldr + col); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+                    st4(Cz + o, v);
+                    const float4 y = ld4(p.bn_y + o);
+                    bsb[0] += v.x; bsb[1] += v.y; bsb[2] += v.z; bsb[3] += v.w;
+                    bk0[0] = fmaf(v.x, (y.x - bmu[0]) * bis[0], bk0[0]); bk0[1] = fmaf(v.y, (y.y - bmu[1]) * bis[1], bk0[1]);
+                    bk0[2] = fmaf(v.z, (y.z - bmu[2]) * bis[2], bk0[2]); bk0[3] = fmaf(v.w, (y.w - bmu[3]) * bis[3], bk0[3]);
                 } else if (EPI == EPI_BNBWD) {
                     if (p.R) { const float4 q = ld4(p.R + (size_t)row * p.ldr + col); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
                     const float4 y = ld4(p.bn_y + o);
@@ -312,6 +332,22 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
         __syncthreads();
     }
 
+    if (EPI == EPI_GSTATS) {
+        float* cs = lds;                              // the image is free: the last half's barrier has passed
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cs[(tid >> 5) * 128 + ((tid & 31) << 2) + e] = bsb[e];
+            cs[1024 + (tid >> 5) * 128 + ((tid & 31) << 2) + e] = bk0[e];
+        }
+        __syncthreads();
+        const int c = tid & 127, which = tid >> 7;     // threads 0..127: sum G, 128..255: sum G*xhat
+        if (n0 + c < p.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += cs[which * 1024 + q * 128 + c];
+            p.gpart[((size_t)tile_m * 2 + which) * p.N + n0 + c] = t;
+        }
+    }
     if (EPI == EPI_BNBWD) {
         // column sums of dPre over this tile's rows: 8 row groups (tid >> 5) per column quad -> LDS -> one thread per column
         float* cs = lds;                              // the image is free: the last half's barrier has passed

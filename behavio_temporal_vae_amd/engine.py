@@ -81,6 +81,10 @@ class Saved:
     x_shift: Optional[torch.Tensor] = None
     x_products: Optional[BwdProducts] = None # Normed input: where this unit's weight gradient leaves its by-products
     out_products: Optional[BwdProducts] = None   # this unit returned a Normed: by-products its consumers fill
+    x_src: Optional["Saved"] = None          # record of the BatchNorm unit that wrote this unit's (materialised) input
+    readers: int = 0                         # Linears that read this unit's materialised output in the forward
+    readers_done: int = 0                    # of which have run their dX product in the backward
+    g_partials: Optional[tuple] = None       # (partials, row tiles) of sum G, sum G*xhat left by the last reader's dX product
 
 
 class NetPlan:
@@ -172,6 +176,7 @@ def _check_train_supported(u: Unit, train: bool):
 
 FOLD_BN_INTO_CONSUMER = True     # train mode: leave BatchNorm outputs that only feed plain Linears unmaterialised
 BWD_SUMS_FROM_CONSUMERS = True   # ... and take their backward column sums from those Linears' weight gradients
+BWD_SUMS_IN_DGRAD = not __import__('os').environ.get('BTVAE_NO_DGRAD_SUMS')   # reduction pass of the other units' BatchNorm backward in the dX product that forms G
 BWD_FUSED_INTO_CONSUMER = not __import__('os').environ.get('BTVAE_NO_FUSED_BWD')   # ... and run their BatchNorm backward in the epilogue of the last such Linear's dX product
 
 
@@ -201,6 +206,9 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
     if isinstance(x, Normed) and (u.residual or not train):
         raise RuntimeError("a residual unit needs its input materialised")
     x_pr = x.products if isinstance(x, Normed) else None
+    x_src = getattr(x, "_btvae_src", None) if (train and saved is not None and not isinstance(x, Normed)) else None
+    if x_src is not None:
+        x_src.readers += 1
     x, W, b, x_sc, x_sh = _linear_operands(u.lin, x)
     if u.bn is not None and train:
         if M * (BN_SYNC.world if BN_SYNC is not None else 1) <= 1:
@@ -230,7 +238,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         normed = keep_normed and FOLD_BN_INTO_CONSUMER and keep is None and not u.residual
         out_pr = BwdProducts(N, dev) if (normed and saved is not None) else None
         if saved is not None:
-            saved.append(Saved(x, y, mean, invstd, keep, ks, total_rows, x_sc, x_sh, x_pr, out_pr))
+            saved.append(Saved(x, y, mean, invstd, keep, ks, total_rows, x_sc, x_sh, x_pr, out_pr, x_src))
             if out_pr is not None:
                 out_pr.owner = (u, saved[-1])
         if normed:
@@ -238,6 +246,8 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         out = torch.empty(M, N, device=dev)
         nv.call("btvae_bn_apply_fwd", P(y), P(mean), P(invstd), P(u.bn.weight), P(u.bn.bias), P(x) if u.residual else None,
                 P(keep), ks, P(out), M, N)
+        if saved is not None and keep is None:
+            out._btvae_src = saved[-1]            # lets the Linear that reads `out` find this unit's record in the backward
     elif u.bn is None and train:
         # unit built without BatchNorm: y = relu(x W^T + b) is what the backward needs; dropout / residual on top
         y = torch.empty(M, N, device=dev)
@@ -251,7 +261,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         else:
             out = y
         if saved is not None:
-            saved.append(Saved(x, y, None, None, keep, ks, 0, x_sc, x_sh, x_pr))
+            saved.append(Saved(x, y, None, None, keep, ks, 0, x_sc, x_sh, x_pr, None, x_src))
     else:
         out = torch.empty(M, N, device=dev)
         scale = shift = None
@@ -270,6 +280,9 @@ def head_forward(u: Unit, x, act: int, lo: float, hi: float, want_dfac: bool, wa
     N = u.lin.out_features
     dev = x.device
     x_pr = x.products if isinstance(x, Normed) else None
+    src = getattr(x, "_btvae_src", None) if not isinstance(x, Normed) else None
+    if src is not None:
+        src.readers += 1                      # its dX product does not leave the sums: the producer falls back to its reduction pass
     a, W, b, x_sc, x_sh = _linear_operands(u.lin, x)
     val = torch.empty(M, N, device=dev)
     dfac = torch.empty(M, N, device=dev) if want_dfac else None
@@ -407,6 +420,15 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
             BN_SYNC.sum_(sums)
         nv.call("btvae_bn_relu_bwd_apply", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), None, 1.0,
                 P(sums), int(max(sv.total_rows, M)), P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
+    elif sv.g_partials is not None:
+        # the dX product that formed g left the per-tile column sums of g and g*xhat: no reduction pass over g and y
+        part, tiles = sv.g_partials
+        sums = torch.empty(2, N, device=dev)
+        nv.call("btvae_bn_bwd_sums_from_partials", P(part), tiles, N, P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)), P(sums), int(accumulate))
+        if sv.total_rows > M:
+            BN_SYNC.sum_(sums)
+        nv.call("btvae_bn_relu_bwd_apply", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), None, 1.0,
+                P(sums), int(max(sv.total_rows, M)), P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
     elif sv.total_rows > M:
         # statistics span ranks: local column sums -> sum over ranks -> dPre with the batch-wide sums
         sums = torch.empty(2, N, device=dev)
@@ -432,7 +454,17 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
     if _fusable(sv.x_products):
         return _dgrad_with_producer_backward(sv.x_products, dpre, u.lin.weight, r, accumulate)
     dx = torch.empty(M, K, device=dev)
-    nv.call("btvae_linear_dgrad", P(dpre), P(u.lin.weight), P(r), P(dx), K, M, N, K)
+    src = sv.x_src
+    if src is not None:
+        src.readers_done += 1
+    if (BWD_SUMS_IN_DGRAD and src is not None and src.readers_done == src.readers and src.mean is not None and src.keep is None
+            and src.out_products is None and K % 4 == 0):
+        tiles = (M + 127) // 128
+        part = torch.empty(tiles, 2, K, device=dev)
+        nv.call("btvae_linear_dgrad_gstats", P(dpre), P(u.lin.weight), P(r), P(src.y), P(src.mean), P(src.invstd), P(dx), P(part), M, N, K)
+        src.g_partials = (part, tiles)
+    else:
+        nv.call("btvae_linear_dgrad", P(dpre), P(u.lin.weight), P(r), P(dx), K, M, N, K)
     return dx
 
 

@@ -135,6 +135,13 @@ int btvae_linear_wgrad_affine(const float* dY, const float* Y, int ldy, const fl
 int btvae_linear_dgrad_bnbwd(const float* dY, const float* W, const float* R, const float* Yb, const float* mean,
                              const float* invstd, const float* gamma, const float* sums, long long total_rows,
                              float* dPre, float* colpart, int M, int N, int K, void* stream);
+/* dX product that also leaves the reduction pass of the BatchNorm backward of the unit whose output it differentiates
+ * (units read through a residual connection, whose sums do not follow from weight gradients): gpart[ceil(M/128)][2][K],
+ * finished by btvae_bn_bwd_sums_from_partials into sums[2][K] (+ dgamma, dbeta); then btvae_bn_relu_bwd_apply. */
+int btvae_linear_dgrad_gstats(const float* dY, const float* W, const float* R, const float* Yb, const float* mean,
+                              const float* invstd, float* dX, float* gpart, int M, int N, int K, void* stream);
+int btvae_bn_bwd_sums_from_partials(const float* partials, int nchunks, int N, float* dgamma, float* dbeta, float* sums,
+                                    int accumulate, void* stream);
 int btvae_colsum_partials(const float* partials, int nchunks, int N, float* out, float* cur, int accumulate, void* stream);
 int btvae_bn_bwd_sums_from_products(const float* col_wp, const float* col_wb, const float* mean, const float* invstd,
                                     float* dgamma, float* dbeta, float* sums, int N, int accumulate, void* stream);

@@ -186,6 +186,30 @@ def test_dgrad_fused_with_batchnorm_backward(dev, gemm_mode, M, N, K, with_r):
     close(db, 1 + ref.sum(0), 1e-4, scale * 1e-5 * math.sqrt(M) * math.sqrt(N), "dbias accumulated")
 
 
+@pytest.mark.parametrize("M,N,K,with_r", [(300, 1000, 1000, True), (130, 72, 48, False)])
+def test_dgrad_with_batchnorm_backward_sums(dev, gemm_mode, M, N, K, with_r):
+    """dX product that also leaves sum G and sum G*xhat per column (per row tile, then merged) against fp64."""
+    dY = rnd(M, N, seed=31); W = rnd(N, K, seed=32) * 0.1
+    R = rnd(M, K, seed=33) if with_r else None
+    Yb = torch.relu(rnd(M, K, seed=34) + 0.2)
+    mean = Yb.mean(0); inv = 1 / torch.sqrt(Yb.var(0, unbiased=False) + 1e-5)
+    G = dY @ W + (R if with_r else 0)
+    xhat = (Yb - mean) * inv
+    f = lambda t: None if t is None else t.float().to(dev).contiguous()
+    d = {k: f(v) for k, v in dict(dY=dY, W=W, R=R, Yb=Yb, mean=mean, inv=inv).items()}
+    tiles = (M + 127) // 128
+    dx, part = torch.empty(M, K, device=dev), torch.empty(tiles, 2, K, device=dev)
+    nv.call("btvae_linear_dgrad_gstats", P(d["dY"]), P(d["W"]), P(d["R"]), P(d["Yb"]), P(d["mean"]), P(d["inv"]), P(dx), P(part), M, N, K)
+    close(dx, G, 2e-6, 2e-6 * math.sqrt(N), "G")
+    sums, dgam, dbet = torch.empty(2, K, device=dev), torch.ones(K, device=dev), torch.ones(K, device=dev)
+    nv.call("btvae_bn_bwd_sums_from_partials", P(part), tiles, K, P(dgam), P(dbet), P(sums), 1)
+    s = math.sqrt(M) * (1 + float(inv.max()))
+    close(sums[0], G.sum(0), 1e-5, 3e-6 * s, "sum G")
+    close(sums[1], (G * xhat).sum(0), 1e-5, 3e-6 * s * 3, "sum G*xhat")
+    close(dbet, 1 + G.sum(0), 1e-5, 3e-6 * s, "dbeta accumulated")
+    close(dgam, 1 + (G * xhat).sum(0), 1e-5, 3e-6 * s * 3, "dgamma accumulated")
+
+
 def test_matmul_bias_and_mul(dev):
     M, K, N = 260, 100, 1176
     A, B, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
