@@ -27,9 +27,13 @@ _SIGS = {
     "btvae_prof_dominant": [I, P, P, P],
     "btvae_set_gemm_precision": [I],
     "btvae_linear_relu_stats_fwd": [P, I, P, P, P, P, I, I, I, P],
+    "btvae_linear_relu_stats_fwd_pw": [P, I, P, P, P, P, P, I, I, I, P],
     "btvae_linear_relu_affine_fwd": [P, I, P, P, P, P, P, P, I, I, I, P],
+    "btvae_linear_relu_affine_fwd_pw": [P, I, P, P, P, P, P, P, P, I, I, I, P],
+    "btvae_weight_planes": [P, I, I, I, P, P],
     "btvae_linear_head_fwd": [P, I, P, P, I, F, F, P, P, P, I, I, I, P],
     "btvae_linear_dgrad": [P, P, P, P, I, I, I, I, P],
+    "btvae_linear_dgrad_pw": [P, P, P, P, P, I, I, I, I, P],
     "btvae_linear_wgrad": [P, P, I, P, P, LL, I, I, I, I, P],
     "btvae_matmul_tn": [P, I, P, I, P, P, LL, I, I, I, I, I, P],
     "btvae_matmul_nt_bias": [P, I, P, I, P, P, I, I, I, I, P],
@@ -44,8 +48,10 @@ _SIGS = {
     "btvae_linear_wgrad_affine": [P, P, I, P, P, P, P, P, P, I, P, P, LL, I, I, I, I, P],
     "btvae_bn_bwd_sums_from_products": [P, P, P, P, P, P, P, I, I, P],
     "btvae_linear_dgrad_bnbwd": [P, P, P, P, P, P, P, P, LL, P, P, I, I, I, P],
+    "btvae_linear_dgrad_bnbwd_pw": [P, P, P, P, P, P, P, P, P, LL, P, P, I, I, I, P],
     "btvae_colsum_partials": [P, I, I, P, P, I, P],
     "btvae_linear_dgrad_gstats": [P, P, P, P, P, P, P, P, I, I, I, P],
+    "btvae_linear_dgrad_gstats_pw": [P, P, P, P, P, P, P, P, P, I, I, I, P],
     "btvae_bn_bwd_sums_from_partials": [P, I, I, P, P, P, I, P],
     "btvae_bn_stats_local": [P, I, I, I, P, P],
     "btvae_bn_stats_merge": [P, I, I, I, P, P, P, P, F, F, P],
@@ -79,6 +85,7 @@ _RET = {
     "btvae_version": (c_int, []),
     "btvae_strip_chunks": (c_int, [I]),
     "btvae_bn_relu_bwd_scratch": (c_longlong, [I, I]),
+    "btvae_weight_planes_elems": (c_longlong, [I, I]),
 }
 EXPORTS = sorted(list(_SIGS) + list(_RET))
 PROF_KINDS = ["gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_mvn", "bn", "mvn_rows", "reduce", "optim"]

@@ -344,6 +344,51 @@ __global__ __launch_bounds__(256) void cols_finalize_kernel(const float* __restr
     }
 }
 
+// fp32 matrix W[R][C] (row pitch ldw) -> its high / middle / low bf16 pieces as the tile images the split kernel stages:
+// image F (W rows = output columns, reduction along a row; the forward products): blocks [ceil(R/128)][ceil(C/16)][3][2048],
+// element (row r, k) of a block at s_off(r, k >> 3) + (k & 7); image D (W rows = reduction index; the dX products):
+// blocks [ceil(C/128)][ceil(R/16)][3][2048], element (k row, column) at 128 * row + column.  Zero padded.
+// One thread per 8 consecutive elements of a row, first of image F, then of image D.
+__global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restrict__ W, int ldw, int R, int C,
+                                                            unsigned short* __restrict__ planes) {
+    const int FT = (R + 127) / 128, FK = (C + 15) / 16, DT = (C + 127) / 128, DK = (R + 15) / 16;
+    const size_t nF = (size_t)FT * FK * 256, nD = (size_t)DT * DK * 256;
+    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nF + nD) return;
+    int r, c0;
+    unsigned short* dst;
+    if (idx < nF) {
+        const size_t blk = idx >> 8; const int t = (int)(idx & 255);
+        const int row = t >> 1, half = t & 1;
+        r = (int)(blk / FK) * 128 + row; c0 = (int)(blk % FK) * 16 + half * 8;
+        dst = planes + blk * (3 * SPLANE) + s_off(row, half);
+    } else {
+        idx -= nF;
+        const size_t blk = idx >> 8; const int t = (int)(idx & 255);
+        const int row = t >> 4, seg = t & 15;
+        r = (int)(blk % DK) * 16 + row; c0 = (int)(blk / DK) * 128 + seg * 8;
+        dst = planes + nF * 24 + blk * (3 * SPLANE) + row * 128 + seg * 8;
+    }
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (r < R && c0 + i < C) ? W[(size_t)r * ldw + c0 + i] : 0.f;
+    unsigned H[4], M[4], L[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split2(v[2 * i], v[2 * i + 1], H[i], M[i], L[i]);
+    *reinterpret_cast<uint4*>(dst) = make_uint4(H[0], H[1], H[2], H[3]);
+    *reinterpret_cast<uint4*>(dst + SPLANE) = make_uint4(M[0], M[1], M[2], M[3]);
+    *reinterpret_cast<uint4*>(dst + 2 * SPLANE) = make_uint4(L[0], L[1], L[2], L[3]);
+}
+
+inline long long planes_f_elems(int N, int K) { return (long long)((N + 127) / 128) * ((K + 15) / 16) * 3 * SPLANE; }
+inline long long planes_d_elems(int N, int K) { return (long long)((K + 127) / 128) * ((N + 15) / 16) * 3 * SPLANE; }
+
+// which kernels exist with a pre-split B operand: the Linear forward products and the dX products
+template <int AL, int BL, int EPI> constexpr bool has_presplit() {
+    return AL == LAY_K && ((BL == LAY_K && (EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE)) ||
+                           (BL == LAY_M && (EPI == EPI_PLAIN || EPI == EPI_BNBWD || EPI == EPI_GSTATS)));
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 std::atomic<int> g_precision{0};   // 0: fp32 MFMA, 1: bf16 operands, 2: fp32 operands as three bf16 pieces (Linear layers only)
@@ -374,7 +419,13 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     splits = (a.K + a.kchunk - 1) / a.kchunk;
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)splits);
     if (bf16)                    hipLaunchKernelGGL((gemm_bf16_mfma<AL, BL, EPI>), grid, dim3(256), 0, s, a);
-    else if (split)              hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI>), grid, dim3(256), 0, s, a);
+    else if (split) {
+        bool pre = false;
+        if constexpr (has_presplit<AL, BL, EPI>()) {
+            if (a.Bp) { pre = true; hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI, true>), grid, dim3(256), 0, s, a); }
+        }
+        if (!pre) hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI>), grid, dim3(256), 0, s, a);
+    }
     else if (a.a_vec && a.b_vec) hipLaunchKernelGGL((gemm_f32_mfma<AL, BL, EPI, true>), grid, dim3(256), 0, s, a);
     else                    hipLaunchKernelGGL((gemm_f32_mfma<AL, BL, EPI, false>), grid, dim3(256), 0, s, a);
     return btvae::check_launch(what);
@@ -406,24 +457,62 @@ BTVAE_API int btvae_set_gemm_precision(int mode) {
 }
 BTVAE_API int btvae_get_gemm_precision(void) { return g_precision.load(std::memory_order_relaxed); }
 
+// Pre-split weights.  A weight matrix W[N][K] that many products reuse can be split into its three bf16 pieces once
+// (btvae_weight_planes) instead of by every workgroup of every product: the *_pw entry points below take the planes
+// next to W and, in the split mode, read the weight operand from them.  The planes are a copy: refresh them whenever
+// W changes.  They hold two tile-ordered images (one for the forward products, one for the dX products), 12 bytes per
+// padded weight element in all; 16-byte aligned base.
+BTVAE_API long long btvae_weight_planes_elems(int N, int K) {
+    if (N <= 0 || K <= 0) return 0;
+    return planes_f_elems(N, K) + planes_d_elems(N, K);
+}
+
+BTVAE_API int btvae_weight_planes(const float* W, int ldw, int N, int K, void* planes, void* stream) {
+    BTVAE_REQUIRE(W && planes, "weight_planes: null pointer");
+    BTVAE_REQUIRE(N > 0 && K > 0 && ldw >= K, "weight_planes: bad shape N=%d K=%d ldw=%d", N, K, ldw);
+    BTVAE_REQUIRE(aligned16(planes), "weight_planes: planes must be 16-byte aligned");
+    const size_t threads = (size_t)(btvae_weight_planes_elems(N, K) / 24);
+    hipLaunchKernelGGL(weight_planes_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       W, ldw, N, K, (unsigned short*)planes);
+    return check_launch("weight_planes");
+}
+
+namespace {
+// attach the planes of W[N][K] (null: none) as the pre-split B operand of a forward (W rows = output columns) or dX
+// (W rows = reduction index) product
+inline void set_planes(GemmArgs& a, const void* planes, int N, int K, bool dx) {
+    if (!planes || !aligned16(planes)) return;
+    a.Bp = (const unsigned short*)planes + (dx ? planes_f_elems(N, K) : 0);
+    a.bp_tiles = dx ? (N + 15) / 16 : (K + 15) / 16;
+}
+}  // namespace
+
 // Y = relu(X W^T + b), plus per-128-row-tile column (mean, M2) partials for BatchNorm statistics.
-BTVAE_API int btvae_linear_relu_stats_fwd(const float* X, int ldx, const float* W, const float* b, float* Y,
-                                          float* stat_partials, int M, int K, int N, void* stream) {
+BTVAE_API int btvae_linear_relu_stats_fwd_pw(const float* X, int ldx, const float* W, const void* Wplanes, const float* b, float* Y,
+                                             float* stat_partials, int M, int K, int N, void* stream) {
     BTVAE_REQUIRE(b && stat_partials, "linear_relu_stats_fwd: null bias/stats");
     GemmArgs a{}; a.A = X; a.lda = ldx; a.B = W; a.ldb = K; a.C = Y; a.ldc = N; a.M = M; a.N = N; a.K = K;
-    a.bias = b; a.stats = stat_partials;
+    a.bias = b; a.stats = stat_partials; set_planes(a, Wplanes, N, K, false);
     ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     return launch<LAY_K, LAY_K, EPI_RELU_STATS>(a, 1, (hipStream_t)stream, "linear_relu_stats_fwd", true);
 }
+BTVAE_API int btvae_linear_relu_stats_fwd(const float* X, int ldx, const float* W, const float* b, float* Y,
+                                          float* stat_partials, int M, int K, int N, void* stream) {
+    return btvae_linear_relu_stats_fwd_pw(X, ldx, W, nullptr, b, Y, stat_partials, M, K, N, stream);
+}
 
 // Out = relu(X W^T + b) * scale + shift (+ R): Linear+ReLU+eval-mode BatchNorm(+residual) in one pass.
-BTVAE_API int btvae_linear_relu_affine_fwd(const float* X, int ldx, const float* W, const float* b, const float* scale,
-                                           const float* shift, const float* R, float* Out, int M, int K, int N, void* stream) {
+BTVAE_API int btvae_linear_relu_affine_fwd_pw(const float* X, int ldx, const float* W, const void* Wplanes, const float* b, const float* scale,
+                                              const float* shift, const float* R, float* Out, int M, int K, int N, void* stream) {
     BTVAE_REQUIRE(b, "linear_relu_affine_fwd: null bias");
     GemmArgs a{}; a.A = X; a.lda = ldx; a.B = W; a.ldb = K; a.C = Out; a.ldc = N; a.M = M; a.N = N; a.K = K;
-    a.bias = b; a.scale = scale; a.shift = shift; a.R = R; a.ldr = N;
+    a.bias = b; a.scale = scale; a.shift = shift; a.R = R; a.ldr = N; set_planes(a, Wplanes, N, K, false);
     ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     return launch<LAY_K, LAY_K, EPI_RELU_AFFINE>(a, 1, (hipStream_t)stream, "linear_relu_affine_fwd", true);
+}
+BTVAE_API int btvae_linear_relu_affine_fwd(const float* X, int ldx, const float* W, const float* b, const float* scale,
+                                           const float* shift, const float* R, float* Out, int M, int K, int N, void* stream) {
+    return btvae_linear_relu_affine_fwd_pw(X, ldx, W, nullptr, b, scale, shift, R, Out, M, K, N, stream);
 }
 
 // Head output layer: raw = X W^T + b; act 0: clamp, 1: clamp(softplus), 2: clamp(relu).
@@ -450,11 +539,14 @@ BTVAE_API int btvae_linear_head_fwd(const float* X, int ldx, const float* W, con
 }
 
 // dX[M,K] = dY[M,N] W[N,K] (+ R[M,K]).
-BTVAE_API int btvae_linear_dgrad(const float* dY, const float* W, const float* R, float* dX, int lddx, int M, int N, int K, void* stream) {
+BTVAE_API int btvae_linear_dgrad_pw(const float* dY, const float* W, const void* Wplanes, const float* R, float* dX, int lddx, int M, int N, int K, void* stream) {
     GemmArgs a{}; a.A = dY; a.lda = N; a.B = W; a.ldb = K; a.C = dX; a.ldc = lddx; a.M = M; a.N = K; a.K = N;
-    a.R = R; a.ldr = lddx;
+    a.R = R; a.ldr = lddx; set_planes(a, Wplanes, N, K, true);
     ProfScope ps(PK_GEMM_DGRAD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * N + (double)N * K + (double)M * K));
     return launch<LAY_K, LAY_M, EPI_PLAIN>(a, 1, (hipStream_t)stream, "linear_dgrad", true);
+}
+BTVAE_API int btvae_linear_dgrad(const float* dY, const float* W, const float* R, float* dX, int lddx, int M, int N, int K, void* stream) {
+    return btvae_linear_dgrad_pw(dY, W, nullptr, R, dX, lddx, M, N, K, stream);
 }
 
 // dX-side product fused with the BatchNorm+ReLU backward of the unit whose output X = BN(relu(.)) the Linear read:
@@ -462,32 +554,41 @@ BTVAE_API int btvae_linear_dgrad(const float* dY, const float* W, const float* R
 // dPre[M,K] = (Yb > 0) * gamma*invstd * (G - sums[0]/rows - xhat*sums[1]/rows), xhat = (Yb - mean)*invstd, and
 // colpart[ceil(M/128)][K] = per-row-tile column sums of dPre (the bias gradient after btvae_colsum_partials).
 // sums[2][K] must be final before the call (btvae_bn_bwd_sums_from_products).  K % 4 == 0 and 16-byte aligned tensors.
-BTVAE_API int btvae_linear_dgrad_bnbwd(const float* dY, const float* W, const float* R, const float* Yb, const float* mean,
-                                       const float* invstd, const float* gamma, const float* sums, long long total_rows,
-                                       float* dPre, float* colpart, int M, int N, int K, void* stream) {
+BTVAE_API int btvae_linear_dgrad_bnbwd_pw(const float* dY, const float* W, const void* Wplanes, const float* R, const float* Yb, const float* mean,
+                                          const float* invstd, const float* gamma, const float* sums, long long total_rows,
+                                          float* dPre, float* colpart, int M, int N, int K, void* stream) {
     BTVAE_REQUIRE(Yb && mean && invstd && gamma && sums && dPre && colpart, "linear_dgrad_bnbwd: null pointer");
     BTVAE_REQUIRE(total_rows >= M, "linear_dgrad_bnbwd: total_rows %lld < local rows %d", total_rows, M);
     BTVAE_REQUIRE(K % 4 == 0 && aligned16(dPre) && aligned16(Yb) && (!R || aligned16(R)), "linear_dgrad_bnbwd: needs K %% 4 == 0 and 16-byte aligned tensors");
     GemmArgs a{}; a.A = dY; a.lda = N; a.B = W; a.ldb = K; a.C = dPre; a.ldc = K; a.M = M; a.N = K; a.K = N;
     a.R = R; a.ldr = K;
     a.bn_y = Yb; a.bn_mean = mean; a.bn_invstd = invstd; a.bn_gamma = gamma; a.bn_sums = sums; a.bn_inv_rows = 1.f / (float)total_rows;
-    a.colpart = colpart;
+    a.colpart = colpart; set_planes(a, Wplanes, N, K, true);
     ProfScope ps(PK_GEMM_DGRAD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * N + (double)N * K + 2.0 * M * K));
     return launch<LAY_K, LAY_M, EPI_BNBWD>(a, 1, (hipStream_t)stream, "linear_dgrad_bnbwd", true);
+}
+BTVAE_API int btvae_linear_dgrad_bnbwd(const float* dY, const float* W, const float* R, const float* Yb, const float* mean,
+                                       const float* invstd, const float* gamma, const float* sums, long long total_rows,
+                                       float* dPre, float* colpart, int M, int N, int K, void* stream) {
+    return btvae_linear_dgrad_bnbwd_pw(dY, W, nullptr, R, Yb, mean, invstd, gamma, sums, total_rows, dPre, colpart, M, N, K, stream);
 }
 
 // dX[M,K] = dY[M,N] W[N,K] (+ R) = the gradient G reaching a BatchNorm output, plus the reduction pass of that
 // BatchNorm's backward from the same epilogue: gpart[ceil(M/128)][2][K] = per-row-tile column sums of G and G*xhat,
 // xhat = (Yb - mean) * invstd (finished by btvae_bn_bwd_sums_from_partials).  K % 4 == 0, 16-byte aligned tensors.
-BTVAE_API int btvae_linear_dgrad_gstats(const float* dY, const float* W, const float* R, const float* Yb, const float* mean,
-                                        const float* invstd, float* dX, float* gpart, int M, int N, int K, void* stream) {
+BTVAE_API int btvae_linear_dgrad_gstats_pw(const float* dY, const float* W, const void* Wplanes, const float* R, const float* Yb, const float* mean,
+                                           const float* invstd, float* dX, float* gpart, int M, int N, int K, void* stream) {
     BTVAE_REQUIRE(Yb && mean && invstd && dX && gpart, "linear_dgrad_gstats: null pointer");
     BTVAE_REQUIRE(K % 4 == 0 && aligned16(dX) && aligned16(Yb) && (!R || aligned16(R)), "linear_dgrad_gstats: needs K %% 4 == 0 and 16-byte aligned tensors");
     GemmArgs a{}; a.A = dY; a.lda = N; a.B = W; a.ldb = K; a.C = dX; a.ldc = K; a.M = M; a.N = K; a.K = N;
     a.R = R; a.ldr = K;
-    a.bn_y = Yb; a.bn_mean = mean; a.bn_invstd = invstd; a.gpart = gpart;
+    a.bn_y = Yb; a.bn_mean = mean; a.bn_invstd = invstd; a.gpart = gpart; set_planes(a, Wplanes, N, K, true);
     ProfScope ps(PK_GEMM_DGRAD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * N + (double)N * K + 2.0 * M * K));
     return launch<LAY_K, LAY_M, EPI_GSTATS>(a, 1, (hipStream_t)stream, "linear_dgrad_gstats", true);
+}
+BTVAE_API int btvae_linear_dgrad_gstats(const float* dY, const float* W, const float* R, const float* Yb, const float* mean,
+                                        const float* invstd, float* dX, float* gpart, int M, int N, int K, void* stream) {
+    return btvae_linear_dgrad_gstats_pw(dY, W, nullptr, R, Yb, mean, invstd, dX, gpart, M, N, K, stream);
 }
 
 // C[M,N] (+)= A^T B with A stored [K][M] (lda) and B stored [K][N] (ldb); the reduction is split over

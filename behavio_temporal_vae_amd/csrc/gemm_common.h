@@ -36,6 +36,9 @@ struct GemmArgs {
     // EPI_GSTATS: the product (+R) = G is written as is; gpart[tiles_m][2][N] = per-row-tile column sums of G and of
     // G*xhat, xhat = (bn_y - bn_mean) * bn_invstd (the reduction pass of that BatchNorm's backward)
     float* gpart;
+    // split kernel only: B pre-split into bf16 planes stored tile by tile (null: split B in the kernel); bp_tiles =
+    // 16-k tiles per tile of output columns
+    const unsigned short* Bp; int bp_tiles;
     int a_vec, b_vec;
     int c_vec;                  // outputs / add-ins allow 16-byte row accesses: epilogue staged through LDS
     int tiles_m, tiles_n;

@@ -49,6 +49,7 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& H, unsigned
 }
 
 struct SStage { float v[8]; };           // 8 staged fp32 values per thread and operand
+struct PStage { unsigned v[12]; };       // pre-split B operand: 8 staged bf16 values of each plane per thread
 
 __device__ __forceinline__ void sput4(SStage& st, int slot, const float4 a) {
     st.v[4 * slot] = a.x; st.v[4 * slot + 1] = a.y; st.v[4 * slot + 2] = a.z; st.v[4 * slot + 3] = a.w;
@@ -116,6 +117,30 @@ __device__ __forceinline__ void s_r2s(__bf16* S, int tid, const SStage& st) {
     }
 }
 
+// Pre-split B operand (a weight matrix split once by btvae_weight_planes).  The planes are kept in HBM as the LDS
+// images of the tiles themselves: per (128-wide tile of output columns, 16-k tile) one 12 KiB block = the three planes
+// of 2048 bf16, each in the order the kernel keeps it in LDS (LAY_K: swizzled [128][16] as s_off; LAY_M: [16 k][128]),
+// zero padded, the k tiles of one column tile consecutive.  A thread's share of a plane is the 16 bytes at 8*tid:
+// the loads are fully coalesced, need no bounds (every tile is whole) and go to LDS as they are -- no split arithmetic
+// for this operand.
+__device__ __forceinline__ void p_g2r(const GemmArgs& p, int n0, int k0, int tid, PStage& st) {
+    const unsigned short* src = p.Bp + (size_t)((n0 >> 7) * p.bp_tiles + (k0 >> 4)) * (3 * SPLANE) + (tid << 3);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const uint4 q = *reinterpret_cast<const uint4*>(src + pl * SPLANE);
+        st.v[4 * pl] = q.x; st.v[4 * pl + 1] = q.y; st.v[4 * pl + 2] = q.z; st.v[4 * pl + 3] = q.w;
+    }
+}
+
+template <int LAY>
+__device__ __forceinline__ void p_r2s(__bf16* S, int tid, const PStage& st) {
+    constexpr int PL = LAY == LAY_K ? SPLANE : MPLANE;
+    __bf16* dst = LAY == LAY_K ? S + (tid << 3) : S + (tid >> 4) * MPITCH + ((tid & 15) << 3);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<uint4*>(dst + pl * PL) = make_uint4(st.v[4 * pl], st.v[4 * pl + 1], st.v[4 * pl + 2], st.v[4 * pl + 3]);
+}
+
 // MFMA operand (row = lane & 31 of the 32-row block at `blk`, k = 8*(lane>>5) .. +7) of one plane.
 // k-contiguous plane: one 16-byte read at the lane's swizzled offset `off` = s_off(blk + (lane&31), lane>>5).
 // m-contiguous plane: two transposing reads; `off` = (8*(lane>>5) + q) * MPITCH + blk + 16*((lane>>4)&1) + 4p with
@@ -143,12 +168,20 @@ __device__ __forceinline__ int s_frag_off(int blk, int lane) {
 #ifndef BTVAE_SPLIT_VPM
 #define BTVAE_SPLIT_VPM 5         // vector instructions of the split scheduled behind each MFMA
 #endif
+#ifndef BTVAE_SPLIT_VPM_PRE
+#define BTVAE_SPLIT_VPM_PRE 5     // the same with a pre-split B operand (half the split arithmetic)
+#endif
 #ifndef BTVAE_SPLIT_WG
 #define BTVAE_SPLIT_WG 2          // workgroups per CU the register budget is set for
 #endif
 
-template <int AL, int BL, int EPI>
+template <bool PRE> struct BStageOf { typedef SStage type; };
+template <> struct BStageOf<true> { typedef PStage type; };
+
+// BPRE: the B operand comes pre-split (p.Bp) instead of as fp32 (p.B).
+template <int AL, int BL, int EPI, bool BPRE = false>
 __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const GemmArgs p) {
+    typedef typename BStageOf<BPRE>::type BStage;
     constexpr int PD = BTVAE_SPLIT_PD;
     constexpr int PLA = plane_elems<AL>(), PLB = plane_elems<BL>();
     __shared__ __attribute__((aligned(16))) __bf16 smem[2][3 * PLA + 3 * PLB];
@@ -176,24 +209,34 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // k-tile j of this workgroup into a register set (no-op past the last tile; full tiles need no predicates)
-    auto fetch = [&](int j, SStage& a, SStage& b) {
+    auto fetch_b = [&](int k0, bool full, BStage& b) {
+        if constexpr (BPRE) p_g2r(p, n0, k0, tid, b);
+        else if (full) s_g2r<BL, true>(p.B, p.ldb, n0, p.N, k0, kend, tid, b);
+        else s_g2r<BL, false>(p.B, p.ldb, n0, p.N, k0, kend, tid, b);
+    };
+    auto publish_b = [&](__bf16* S, const BStage& b) {
+        if constexpr (BPRE) p_r2s<BL>(S, tid, b);
+        else s_r2s<BL>(S, tid, b);
+    };
+    auto fetch = [&](int j, SStage& a, BStage& b) {
         if (j >= nk) return;
         const int k0 = kbeg + j * SBK;
         if (k0 + SBK <= kend) {
             s_g2r<AL, true>(p.A, p.lda, m0, p.M, k0, kend, tid, a);
-            s_g2r<BL, true>(p.B, p.ldb, n0, p.N, k0, kend, tid, b);
+            fetch_b(k0, true, b);
         } else {
             s_g2r<AL, false>(p.A, p.lda, m0, p.M, k0, kend, tid, a);
-            s_g2r<BL, false>(p.B, p.ldb, n0, p.N, k0, kend, tid, b);
+            fetch_b(k0, false, b);
         }
     };
 
     // Register sets: tile j (j >= 1) travels in set j % PD.  Tile 0 goes straight to LDS through set 0.
-    SStage sa[PD], sb[PD];
+    SStage sa[PD];
+    BStage sb[PD];
     if (nk > 0) {
         fetch(0, sa[0], sb[0]);
         s_r2s<AL>(smem[0], tid, sa[0]);
-        s_r2s<BL>(smem[0] + 3 * PLA, tid, sb[0]);
+        publish_b(smem[0] + 3 * PLA, sb[0]);
     }
 #pragma unroll
     for (int j = 1; j <= PD; ++j) fetch(j, sa[j % PD], sb[j % PD]);
@@ -239,15 +282,15 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
             const int cur = t & 1;
             tile_mma(smem[cur], smem[cur] + 3 * PLA);
             s_r2s<AL>(smem[cur ^ 1], tid, sa[(u + 1) % PD]);
-            s_r2s<BL>(smem[cur ^ 1] + 3 * PLA, tid, sb[(u + 1) % PD]);
+            publish_b(smem[cur ^ 1] + 3 * PLA, sb[(u + 1) % PD]);
             const int k0 = kbeg + (t + 1 + PD) * SBK;
             s_g2r<AL, true>(p.A, p.lda, m0, p.M, k0, kend, tid, sa[(u + 1) % PD]);
-            s_g2r<BL, true>(p.B, p.ldb, n0, p.N, k0, kend, tid, sb[(u + 1) % PD]);
+            fetch_b(k0, true, sb[(u + 1) % PD]);
             __builtin_amdgcn_sched_group_barrier(0x100, (AL == LAY_K ? 6 : 12) + (BL == LAY_K ? 6 : 12), 0);   // fragment reads
 #pragma unroll
             for (int k = 0; k < 24; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, BTVAE_SPLIT_VPM, 0);   // a few vector instructions
+                __builtin_amdgcn_sched_group_barrier(0x002, BPRE ? BTVAE_SPLIT_VPM_PRE : BTVAE_SPLIT_VPM, 0);   // a few vector instructions
                 if (k & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // an LDS store
             }
             __syncthreads();
@@ -264,7 +307,7 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < nk) {
                     s_r2s<AL>(smem[cur ^ 1], tid, sa[(u + 1) % PD]);
-                    s_r2s<BL>(smem[cur ^ 1] + 3 * PLA, tid, sb[(u + 1) % PD]);
+                    publish_b(smem[cur ^ 1] + 3 * PLA, sb[(u + 1) % PD]);
                 }
                 fetch(t + 1 + PD, sa[(u + 1) % PD], sb[(u + 1) % PD]);
                 __syncthreads();

@@ -85,6 +85,7 @@ class Saved:
     readers: int = 0                         # Linears that read this unit's materialised output in the forward
     readers_done: int = 0                    # of which have run their dX product in the backward
     g_partials: Optional[tuple] = None       # (partials, row tiles) of sum G, sum G*xhat left by the last reader's dX product
+    w_planes: Optional[torch.Tensor] = None  # bf16 planes of the unit's (unfolded) weight for the dX product, split mode
 
 
 class NetPlan:
@@ -180,6 +181,20 @@ BWD_SUMS_IN_DGRAD = not __import__('os').environ.get('BTVAE_NO_DGRAD_SUMS')   # 
 BWD_FUSED_INTO_CONSUMER = not __import__('os').environ.get('BTVAE_NO_FUSED_BWD')   # ... and run their BatchNorm backward in the epilogue of the last such Linear's dX product
 
 
+PRESPLIT_WEIGHTS = not __import__('os').environ.get('BTVAE_NO_PRESPLIT')   # split mode: weights split into bf16 planes once per pass
+
+
+def _weight_planes(W: torch.Tensor) -> Optional[torch.Tensor]:
+    """bf16 planes of a weight matrix for the ``*_pw`` products (``btvae_weight_planes``), or None outside the split
+    mode.  They are a copy of ``W`` as it is now: made per forward pass, used by that pass and its backward."""
+    if not PRESPLIT_WEIGHTS or nv.lib().btvae_get_gemm_precision() != 2:
+        return None
+    N, K = W.shape
+    planes = torch.empty(nv.lib().btvae_weight_planes_elems(N, K), dtype=torch.int16, device=W.device)
+    nv.call("btvae_weight_planes", P(W), K, N, K, P(planes))
+    return planes
+
+
 def _linear_operands(lin: torch.nn.Linear, x):
     """(A, W, b, scale, shift) of ``lin`` applied to ``x``: a tensor as is, a Normed input through folded weights."""
     if not isinstance(x, Normed):
@@ -210,6 +225,9 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
     if x_src is not None:
         x_src.readers += 1
     x, W, b, x_sc, x_sh = _linear_operands(u.lin, x)
+    wp = _weight_planes(W)
+    # the dX product of the backward reads the unfolded weight
+    wp_bwd = None if saved is None else (wp if W is u.lin.weight else _weight_planes(u.lin.weight))
     if u.bn is not None and train:
         if M * (BN_SYNC.world if BN_SYNC is not None else 1) <= 1:
             # torch.nn.BatchNorm1d refuses a one-row batch in train mode (torch/nn/functional.py, _verify_batch_size)
@@ -217,7 +235,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         tiles = (M + 127) // 128
         y = torch.empty(M, N, device=dev)
         part = WS.get("bnpart", tiles * 2 * N, dev)
-        nv.call("btvae_linear_relu_stats_fwd", P(x), K, P(W), P(b), P(y), P(part), M, K, N)
+        nv.call("btvae_linear_relu_stats_fwd_pw", P(x), K, P(W), P(wp), P(b), P(y), P(part), M, K, N)
         mean, invstd = torch.empty(N, device=dev), torch.empty(N, device=dev)
         track = u.bn.track_running_stats and u.bn.running_mean is not None
         mom = u.bn.momentum if u.bn.momentum is not None else 0.1
@@ -238,7 +256,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         normed = keep_normed and FOLD_BN_INTO_CONSUMER and keep is None and not u.residual
         out_pr = BwdProducts(N, dev) if (normed and saved is not None) else None
         if saved is not None:
-            saved.append(Saved(x, y, mean, invstd, keep, ks, total_rows, x_sc, x_sh, x_pr, out_pr, x_src))
+            saved.append(Saved(x, y, mean, invstd, keep, ks, total_rows, x_sc, x_sh, x_pr, out_pr, x_src, w_planes=wp_bwd))
             if out_pr is not None:
                 out_pr.owner = (u, saved[-1])
         if normed:
@@ -251,7 +269,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
     elif u.bn is None and train:
         # unit built without BatchNorm: y = relu(x W^T + b) is what the backward needs; dropout / residual on top
         y = torch.empty(M, N, device=dev)
-        nv.call("btvae_linear_relu_affine_fwd", P(x), K, P(W), P(b), None, None, None, P(y), M, K, N)
+        nv.call("btvae_linear_relu_affine_fwd_pw", P(x), K, P(W), P(wp), P(b), None, None, None, P(y), M, K, N)
         keep, ks = None, 1.0
         if u.dropout_p > 0.0:
             keep, ks = DROPOUT.keep(M, N, u.dropout_p, dev), 1.0 / (1.0 - u.dropout_p)
@@ -261,21 +279,22 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         else:
             out = y
         if saved is not None:
-            saved.append(Saved(x, y, None, None, keep, ks, 0, x_sc, x_sh, x_pr, None, x_src))
+            saved.append(Saved(x, y, None, None, keep, ks, 0, x_sc, x_sh, x_pr, None, x_src, w_planes=wp_bwd))
     else:
         out = torch.empty(M, N, device=dev)
         scale = shift = None
         if u.bn is not None:
             scale, shift = torch.empty(N, device=dev), torch.empty(N, device=dev)
             nv.call("btvae_bn_fold_eval", P(u.bn.weight), P(u.bn.bias), P(u.bn.running_mean), P(u.bn.running_var), float(u.bn.eps), P(scale), P(shift), N)
-        nv.call("btvae_linear_relu_affine_fwd", P(x), K, P(W), P(b), P(scale), P(shift), P(x) if u.residual else None, P(out), M, K, N)
+        nv.call("btvae_linear_relu_affine_fwd_pw", P(x), K, P(W), P(wp), P(b), P(scale), P(shift), P(x) if u.residual else None, P(out), M, K, N)
     return out
 
 
 def head_forward(u: Unit, x, act: int, lo: float, hi: float, want_dfac: bool, want_sq: bool):
     """Head output Linear fused with its clamp / softplus / relu non-linearity
     (src/submodels.py:102-104,156-157).  ``x`` may be a ``Normed``.
-    Returns (value, dfac or None, value^2 or None, (scale, shift, by-product holder) of a Normed input or Nones)."""
+    Returns (value, dfac or None, value^2 or None, (scale, shift, by-product holder) of a Normed input or Nones,
+    bf16 planes of the weight for the backward's dX product when ``want_dfac`` (split mode) or None)."""
     M, K = x.shape
     N = u.lin.out_features
     dev = x.device
@@ -288,7 +307,7 @@ def head_forward(u: Unit, x, act: int, lo: float, hi: float, want_dfac: bool, wa
     dfac = torch.empty(M, N, device=dev) if want_dfac else None
     sq = torch.empty(M, N, device=dev) if want_sq else None
     nv.call("btvae_linear_head_fwd", P(a), K, P(W), P(b), act, float(lo), float(hi), P(val), P(dfac), P(sq), M, K, N)
-    return val, dfac, sq, (x_sc, x_sh, x_pr)
+    return val, dfac, sq, (x_sc, x_sh, x_pr), (_weight_planes(u.lin.weight) if want_dfac else None)
 
 
 @dataclass
@@ -298,6 +317,7 @@ class NetTape:
     head_in: Dict[str, torch.Tensor] = field(default_factory=dict)   # input of each head's output Linear (a Normed's y)
     head_in_affine: Dict[str, tuple] = field(default_factory=dict)    # (scale, shift) of that input when it was a Normed
     dfac: Dict[str, torch.Tensor] = field(default_factory=dict)
+    head_planes: Dict[str, Optional[torch.Tensor]] = field(default_factory=dict)   # bf16 planes of each head's output weight
 
 
 def net_forward(plan: NetPlan, x: torch.Tensor, train: bool, tape: Optional[NetTape], head_specs: Dict[str, tuple], want_sq=()):
@@ -322,7 +342,7 @@ def net_forward(plan: NetPlan, x: torch.Tensor, train: bool, tape: Optional[NetT
             normed_ok = i + 1 == len(hidden) or not hidden[i + 1].residual
             t = unit_forward(u, t, train, sv, keep_normed=train and normed_ok)
         act, lo, hi = head_specs[name]
-        val, dfac, sq, affine = head_forward(units[-1], t, act, lo, hi, tape is not None, name in want_sq)
+        val, dfac, sq, affine, planes = head_forward(units[-1], t, act, lo, hi, tape is not None, name in want_sq)
         out[name] = val
         if sq is not None:
             sqs[name] = sq
@@ -331,6 +351,7 @@ def net_forward(plan: NetPlan, x: torch.Tensor, train: bool, tape: Optional[NetT
             tape.head_in[name] = t.y if isinstance(t, Normed) else t
             tape.head_in_affine[name] = affine
             tape.dfac[name] = dfac
+            tape.head_planes[name] = planes
     return out, sqs
 
 
@@ -367,7 +388,8 @@ def _fusable(pr: Optional[BwdProducts]) -> bool:
     return pr.consumers > 0 and pr.filled == pr.consumers and sv_p.keep is None and sv_p.y.shape[1] % 4 == 0
 
 
-def _dgrad_with_producer_backward(pr: BwdProducts, dy: torch.Tensor, W: torch.Tensor, r: Optional[torch.Tensor], accumulate: bool):
+def _dgrad_with_producer_backward(pr: BwdProducts, dy: torch.Tensor, W: torch.Tensor, r: Optional[torch.Tensor], accumulate: bool,
+                                  planes: Optional[torch.Tensor] = None):
     """dX product of a Linear that read a Normed, fused with the BatchNorm+ReLU backward of the unit that produced it.
     Returns that unit's dPre (what its own backward continues from); its BatchNorm and bias gradients are written."""
     u_p, sv_p = pr.owner
@@ -382,7 +404,7 @@ def _dgrad_with_producer_backward(pr: BwdProducts, dy: torch.Tensor, W: torch.Te
     tiles = (M + 127) // 128
     dpre = torch.empty(M, Np, device=dev)
     part = WS.get("bnbwd_part", tiles * Np, dev)
-    nv.call("btvae_linear_dgrad_bnbwd", P(dy), P(W), P(r), P(sv_p.y), P(sv_p.mean), P(sv_p.invstd), P(u_p.bn.weight), P(sums),
+    nv.call("btvae_linear_dgrad_bnbwd_pw", P(dy), P(W), P(planes), P(r), P(sv_p.y), P(sv_p.mean), P(sv_p.invstd), P(u_p.bn.weight), P(sums),
             int(max(sv_p.total_rows, M)), P(dpre), P(part), M, N, Np)
     db_cur = torch.empty(Np, device=dev) if sv_p.x_scale is not None else None
     nv.call("btvae_colsum_partials", P(part), tiles, Np, P(_grad_view(u_p.lin.bias)), P(db_cur), int(accumulate))
@@ -452,7 +474,7 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
     elif add_to is not None:
         r = add_to
     if _fusable(sv.x_products):
-        return _dgrad_with_producer_backward(sv.x_products, dpre, u.lin.weight, r, accumulate)
+        return _dgrad_with_producer_backward(sv.x_products, dpre, u.lin.weight, r, accumulate, sv.w_planes)
     dx = torch.empty(M, K, device=dev)
     src = sv.x_src
     if src is not None:
@@ -461,10 +483,10 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
             and src.out_products is None and K % 4 == 0):
         tiles = (M + 127) // 128
         part = torch.empty(tiles, 2, K, device=dev)
-        nv.call("btvae_linear_dgrad_gstats", P(dpre), P(u.lin.weight), P(r), P(src.y), P(src.mean), P(src.invstd), P(dx), P(part), M, N, K)
+        nv.call("btvae_linear_dgrad_gstats_pw", P(dpre), P(u.lin.weight), P(sv.w_planes), P(r), P(src.y), P(src.mean), P(src.invstd), P(dx), P(part), M, N, K)
         src.g_partials = (part, tiles)
     else:
-        nv.call("btvae_linear_dgrad", P(dpre), P(u.lin.weight), P(r), P(dx), K, M, N, K)
+        nv.call("btvae_linear_dgrad_pw", P(dpre), P(u.lin.weight), P(sv.w_planes), P(r), P(dx), K, M, N, K)
     return dx
 
 
@@ -487,10 +509,10 @@ def net_backward(plan: NetPlan, tape: NetTape, draw: Dict[str, torch.Tensor], ne
         nv.call("btvae_colsum", P(d), P(_grad_view(last.lin.bias)), P(db_cur), P(cs), M, N, int(accumulate))
         _wgrad(last.lin, d, t_in, x_sc, x_sh, db_cur, accumulate, x_pr)
         if _fusable(x_pr):
-            g = _dgrad_with_producer_backward(x_pr, d, last.lin.weight, None, accumulate)
+            g = _dgrad_with_producer_backward(x_pr, d, last.lin.weight, None, accumulate, tape.head_planes.get(name))
         else:
             g = torch.empty(M, K, device=dev)
-            nv.call("btvae_linear_dgrad", P(d), P(last.lin.weight), None, P(g), K, M, N, K)
+            nv.call("btvae_linear_dgrad_pw", P(d), P(last.lin.weight), P(tape.head_planes.get(name)), None, P(g), K, M, N, K)
         svs = tape.heads[name]
         for i in range(len(units) - 2, -1, -1):
             first = i == 0

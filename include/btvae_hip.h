@@ -35,13 +35,27 @@ int btvae_prof_dominant(int kind, double* ms, double* flops_per_launch, long lon
 int btvae_set_gemm_precision(int mode);
 int btvae_get_gemm_precision(void);
 
+/* Pre-split weights (mode 2).  Every workgroup of a mode-2 product splits the operand tiles it stages; a weight matrix
+ * W[N,K] (torch.nn.Linear.weight, src/submodels.py:15-17) is re-split by all of them.  btvae_weight_planes splits it once
+ * into `planes`: three bf16 planes [N padded to 16][K padded to 16] (high, middle, low pieces, zero padded, 16-byte
+ * aligned base, btvae_weight_planes_elems(N, K) 2-byte elements in all).  The *_pw variants of the forward and dX
+ * products take the planes next to W and read the weight operand from them in mode 2 (other modes, unaligned operands
+ * and Wplanes == NULL use W as the plain entry points do).  The planes are a copy: call btvae_weight_planes again
+ * whenever W has changed. */
+long long btvae_weight_planes_elems(int N, int K);
+int btvae_weight_planes(const float* W, int ldw, int N, int K, void* planes, void* stream);
+
 /* ---- Linear layers on MFMA (src/submodels.py:15-17 Linear+ReLU, :20-21 BatchNorm1d, :28-35 NNBlock.forward) ---- */
 /* Y[M,N] = relu(X[M,K] W[N,K]^T + b); stat_partials[ceil(M/128)][2][N] = per-row-tile column (mean, M2). */
 int btvae_linear_relu_stats_fwd(const float* X, int ldx, const float* W, const float* b, float* Y,
                                 float* stat_partials, int M, int K, int N, void* stream);
+int btvae_linear_relu_stats_fwd_pw(const float* X, int ldx, const float* W, const void* Wplanes, const float* b, float* Y,
+                                   float* stat_partials, int M, int K, int N, void* stream);
 /* Eval mode: Out = relu(X W^T + b) * scale + shift (+ R); scale/shift/R may be NULL. */
 int btvae_linear_relu_affine_fwd(const float* X, int ldx, const float* W, const float* b, const float* scale,
                                  const float* shift, const float* R, float* Out, int M, int K, int N, void* stream);
+int btvae_linear_relu_affine_fwd_pw(const float* X, int ldx, const float* W, const void* Wplanes, const float* b, const float* scale,
+                                    const float* shift, const float* R, float* Out, int M, int K, int N, void* stream);
 /* Head output Linear + non-linearity (src/submodels.py:102-104,156-157): act 0 clamp(raw,lo,hi),
  * 1 clamp(softplus(raw, threshold 5),lo,hi) (src/utils.py:10), 2 clamp(relu(raw),lo,hi).
  * Dfac = d Out / d raw and Sq = Out^2 are optional outputs (NULL to skip). */
@@ -50,6 +64,7 @@ int btvae_linear_head_fwd(const float* X, int ldx, const float* W, const float* 
 /* dX[M,K] = dY[M,N] W[N,K] (+ R[M,K], same leading dimension lddx).  Replaces autograd's Linear dgrad
  * (src/vae_models.py:322). */
 int btvae_linear_dgrad(const float* dY, const float* W, const float* R, float* dX, int lddx, int M, int N, int K, void* stream);
+int btvae_linear_dgrad_pw(const float* dY, const float* W, const void* Wplanes, const float* R, float* dX, int lddx, int M, int N, int K, void* stream);
 /* dW[N,K] (+)= dY[M,N]^T X[M,K]; ws = split-reduction workspace of ws_floats floats (>= N*K to split). */
 int btvae_linear_wgrad(const float* dY, const float* X, int ldx, float* dW, float* ws, long long ws_floats,
                        int M, int N, int K, int accumulate, void* stream);
@@ -135,11 +150,16 @@ int btvae_linear_wgrad_affine(const float* dY, const float* Y, int ldy, const fl
 int btvae_linear_dgrad_bnbwd(const float* dY, const float* W, const float* R, const float* Yb, const float* mean,
                              const float* invstd, const float* gamma, const float* sums, long long total_rows,
                              float* dPre, float* colpart, int M, int N, int K, void* stream);
+int btvae_linear_dgrad_bnbwd_pw(const float* dY, const float* W, const void* Wplanes, const float* R, const float* Yb, const float* mean,
+                                const float* invstd, const float* gamma, const float* sums, long long total_rows,
+                                float* dPre, float* colpart, int M, int N, int K, void* stream);
 /* dX product that also leaves the reduction pass of the BatchNorm backward of the unit whose output it differentiates
  * (units read through a residual connection, whose sums do not follow from weight gradients): gpart[ceil(M/128)][2][K],
  * finished by btvae_bn_bwd_sums_from_partials into sums[2][K] (+ dgamma, dbeta); then btvae_bn_relu_bwd_apply. */
 int btvae_linear_dgrad_gstats(const float* dY, const float* W, const float* R, const float* Yb, const float* mean,
                               const float* invstd, float* dX, float* gpart, int M, int N, int K, void* stream);
+int btvae_linear_dgrad_gstats_pw(const float* dY, const float* W, const void* Wplanes, const float* R, const float* Yb, const float* mean,
+                                 const float* invstd, float* dX, float* gpart, int M, int N, int K, void* stream);
 int btvae_bn_bwd_sums_from_partials(const float* partials, int nchunks, int N, float* dgamma, float* dbeta, float* sums,
                                     int accumulate, void* stream);
 int btvae_colsum_partials(const float* partials, int nchunks, int N, float* out, float* cur, int accumulate, void* stream);

@@ -210,6 +210,65 @@ def test_dgrad_with_batchnorm_backward_sums(dev, gemm_mode, M, N, K, with_r):
     close(dgam, 1 + (G * xhat).sum(0), 1e-5, 3e-6 * s * 3, "dgamma accumulated")
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 1000, 52), (257, 1000, 1000), (130, 72, 48), (1000, 100, 1000), (70, 36, 33)])
+def test_presplit_weight_products(dev, gemm_mode, M, N, K):
+    """Forward and dX products reading the weight from planes split once (btvae_weight_planes): the planes hold the
+    exact three-way truncation split, zero padded; the products are bit-identical to the entry points that split the
+    weight tile by tile (same pieces, same order of the same MFMAs), in every mode and for shapes that fall back."""
+    X, W, b = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=0.2), rnd(N, seed=43, scale=0.1)
+    dY, R = rnd(M, N, seed=44), rnd(M, K, seed=45)
+    Xd, Wd, bd, dYd, Rd = (t.float().to(dev) for t in (X, W, b, dY, R))
+    n_el = nv.lib().btvae_weight_planes_elems(N, K)
+    FT, FK, DT, DK = (N + 127) // 128, (K + 15) // 16, (K + 127) // 128, (N + 15) // 16
+    assert n_el == (FT * FK + DT * DK) * 3 * 2048
+    planes = torch.full((n_el,), 0x7FC0, dtype=torch.int16, device=dev)
+    nv.call("btvae_weight_planes", P(Wd), K, N, K, P(planes))
+    # pieces: h = W truncated to bf16, m = (W - h) truncated, l = (W - h - m) truncated; all differences exact in fp32
+    Wp = torch.zeros(max(FT * 128, DK * 16), max(FK * 16, DT * 128), device=dev); Wp[:N, :K] = Wd
+    trunc = lambda t: (t.view(torch.int32) & -65536).view(torch.float32)
+    h = trunc(Wp); m = trunc(Wp - h); l = trunc(Wp - h - m)
+    pieces = torch.stack([(p_.view(torch.int32) >> 16).to(torch.int16) for p_ in (h, m, l)])      # [3, rows, cols]
+    # forward image: blocks [FT][FK][3][2048]; element (row, k) of a block at the kernel's swizzled LDS offset
+    row = torch.arange(128, device=dev)[:, None]; kk = torch.arange(16, device=dev)[None, :]
+    pr = (row & ~3) | ((row ^ (row >> 2)) & 3)
+    off = pr * 16 + (((kk >> 3) ^ ((pr >> 3) & 1)) << 3) + (kk & 7)                                  # [128, 16]
+    imgF = planes[:FT * FK * 3 * 2048].view(FT, FK, 3, 2048)
+    wantF = pieces[:, :FT * 128, :FK * 16].reshape(3, FT, 128, FK, 16).permute(1, 3, 0, 2, 4)          # [FT, FK, 3, 128, 16]
+    assert torch.equal(imgF[..., off.reshape(-1)].reshape(FT, FK, 3, 128, 16), wantF), "forward image"
+    # dX image: blocks [DT][DK][3][16 k rows][128 columns]
+    imgD = planes[FT * FK * 3 * 2048:].view(DT, DK, 3, 16, 128)
+    wantD = pieces[:, :DK * 16, :DT * 128].reshape(3, DK, 16, DT, 128).permute(3, 1, 0, 2, 4)
+    assert torch.equal(imgD, wantD), "dX image"
+    tiles = (M + 127) // 128
+    Y0, Y1 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    p0, p1 = torch.empty(tiles, 2, N, device=dev), torch.empty(tiles, 2, N, device=dev)
+    nv.call("btvae_linear_relu_stats_fwd", P(Xd), K, P(Wd), P(bd), P(Y0), P(p0), M, K, N)
+    nv.call("btvae_linear_relu_stats_fwd_pw", P(Xd), K, P(Wd), P(planes), P(bd), P(Y1), P(p1), M, K, N)
+    assert torch.equal(Y0, Y1) and torch.equal(p0, p1), "relu_stats forward"
+    sc, sh = rnd(N, seed=46).float().to(dev), rnd(N, seed=47).float().to(dev)
+    Rn = rnd(M, N, seed=48).float().to(dev)
+    nv.call("btvae_linear_relu_affine_fwd", P(Xd), K, P(Wd), P(bd), P(sc), P(sh), P(Rn), P(Y0), M, K, N)
+    nv.call("btvae_linear_relu_affine_fwd_pw", P(Xd), K, P(Wd), P(planes), P(bd), P(sc), P(sh), P(Rn), P(Y1), M, K, N)
+    assert torch.equal(Y0, Y1), "relu_affine forward"
+    D0, D1 = torch.empty(M, K, device=dev), torch.empty(M, K, device=dev)
+    nv.call("btvae_linear_dgrad", P(dYd), P(Wd), P(Rd), P(D0), K, M, N, K)
+    nv.call("btvae_linear_dgrad_pw", P(dYd), P(Wd), P(planes), P(Rd), P(D1), K, M, N, K)
+    assert torch.equal(D0, D1), "dgrad"
+    close(D1, dYd.cpu().double() @ Wd.cpu().double() + Rd.cpu().double(), 2e-6, 3e-6 * math.sqrt(N), "dgrad vs fp64")
+    if K % 4 == 0:
+        Yb = torch.relu(rnd(M, K, seed=49) + 0.2).float().to(dev)
+        mean, inv = Yb.mean(0), 1 / torch.sqrt(Yb.var(0, unbiased=False) + 1e-5)
+        gam, sums = (1 + 0.3 * rnd(K, seed=50)).float().to(dev), rnd(2, K, seed=51).float().to(dev)
+        c0, c1 = torch.empty(tiles, K, device=dev), torch.empty(tiles, K, device=dev)
+        nv.call("btvae_linear_dgrad_bnbwd", P(dYd), P(Wd), P(Rd), P(Yb), P(mean), P(inv), P(gam), P(sums), M, P(D0), P(c0), M, N, K)
+        nv.call("btvae_linear_dgrad_bnbwd_pw", P(dYd), P(Wd), P(planes), P(Rd), P(Yb), P(mean), P(inv), P(gam), P(sums), M, P(D1), P(c1), M, N, K)
+        assert torch.equal(D0, D1) and torch.equal(c0, c1), "dgrad + BatchNorm backward"
+        g0, g1 = torch.empty(tiles, 2, K, device=dev), torch.empty(tiles, 2, K, device=dev)
+        nv.call("btvae_linear_dgrad_gstats", P(dYd), P(Wd), P(Rd), P(Yb), P(mean), P(inv), P(D0), P(g0), M, N, K)
+        nv.call("btvae_linear_dgrad_gstats_pw", P(dYd), P(Wd), P(planes), P(Rd), P(Yb), P(mean), P(inv), P(D1), P(g1), M, N, K)
+        assert torch.equal(D0, D1) and torch.equal(g0, g1), "dgrad + BatchNorm backward sums"
+
+
 def test_matmul_bias_and_mul(dev):
     M, K, N = 260, 100, 1176
     A, B, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)

@@ -33,7 +33,11 @@ def main():
     dX = torch.empty(M, K, device=dev)
     dW = torch.empty(N, K, device=dev)
     ws = torch.empty(32 * 1024 * 1024, device=dev)
+    planes = torch.empty(nv.lib().btvae_weight_planes_elems(N, K), dtype=torch.int16, device=dev)
+    nv.call("btvae_weight_planes", P(W), K, N, K, P(planes))
     ops = {
+        "fwd_pw": lambda: nv.call("btvae_linear_relu_stats_fwd_pw", P(X), K, P(W), P(planes), P(b), P(Y), P(part), M, K, N),
+        "dgrad_pw": lambda: nv.call("btvae_linear_dgrad_pw", P(Y), P(W), P(planes), None, P(dX), K, M, N, K),
         "fwd": lambda: nv.call("btvae_linear_relu_stats_fwd", P(X), K, P(W), P(b), P(Y), P(part), M, K, N),
         "dgrad": lambda: nv.call("btvae_linear_dgrad", P(Y), P(W), None, P(dX), K, M, N, K),
         "wgrad": lambda: nv.call("btvae_linear_wgrad", P(Y), P(X), K, P(dW), P(ws), ws.numel(), M, N, K, 0),
