@@ -43,7 +43,7 @@ BREAKDOWN_STEPS = 3             # untimed steps with every launch event-timed, f
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X bf16 dense matrix peak (v_mfma_f32_32x32x16_bf16, 1024 FLOP/clk/SIMD)
 SPLIT_TERMS = 6                  # bf16 MFMAs issued per fp32 product in the split mode
 # HBM-side bytes of one launch of the dominant kernel (M=65536, N=K=1000) from PMC passes kept under profiles/
-DOMINANT_KERNEL_HBM_BYTES = {"fp32": 2 * 324658 * 1024 + 304764 * 1024, "fp32_split": 2 * 366460 * 1024 + 260010 * 1024}
+DOMINANT_KERNEL_HBM_BYTES = {"fp32": 2 * 324658 * 1024 + 304764 * 1024, "fp32_split": 2 * 505912 * 1024 + 258478 * 1024}
 
 
 KERNEL_NAME = {"fp32_split": "gemm_split_mfma", "fp32": "gemm_f32_mfma", "bf16": "gemm_bf16_mfma"}
@@ -327,7 +327,7 @@ def main():
                        "gemm_precision": main_precision, "global_batch": world * B,
                        "per_gpu_batch": B, "num_mc_samples": S, "input_dim": D, "cond_dim": C, "latent_dim": 48, "hidden": 1000,
                        "vocab": 100, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": f"{KERNEL_NAME[main_precision]}<k-contig,k-contig,relu+stats> M={S * B} N=K=1000 (decoder hidden Linear forward)",
+            "roofline": {"bound": "mfma", "kernel": f"{KERNEL_NAME[main_precision]}<k-contig,k-contig,relu+stats{',pre-split weight' if main_precision == 'fp32_split' else ''}> M={S * B} N=K=1000 (decoder hidden Linear forward)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": peak_note,
                          "fp32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                          "flops_per_launch": dom_fl, "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
