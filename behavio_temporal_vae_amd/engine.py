@@ -5,13 +5,16 @@ the reference's ``ParameterizerNN``, src/submodels.py:41-69), and for every Line
 unit issues the matching C-ABI calls on the current HIP stream.  torch only provides device buffers.
 
 Forward of one unit in train mode:  GEMM(bias+ReLU, column-statistics epilogue) -> statistics
-finalize -> BatchNorm apply (+ residual).  Eval mode folds BatchNorm into the GEMM epilogue.
-Backward: BatchNorm/ReLU backward (two streaming passes) -> wgrad GEMM (split reduction) -> dgrad
-GEMM whose epilogue adds the residual / second-consumer gradient.
+finalize -> BatchNorm apply (+ residual), or no apply at all when every reader is a plain Linear
+(the reader folds the normalisation into its weights).  Eval mode folds BatchNorm into the GEMM epilogue.
+Backward: BatchNorm/ReLU backward -> wgrad GEMM (split reduction) -> dgrad GEMM whose epilogue adds
+the residual / second-consumer gradient and, where it can, runs the producing unit's BatchNorm
+backward or its reduction pass.  The environment switches below turn the fusions off for A/B runs.
 """
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -177,11 +180,11 @@ def _check_train_supported(u: Unit, train: bool):
 
 FOLD_BN_INTO_CONSUMER = True     # train mode: leave BatchNorm outputs that only feed plain Linears unmaterialised
 BWD_SUMS_FROM_CONSUMERS = True   # ... and take their backward column sums from those Linears' weight gradients
-BWD_SUMS_IN_DGRAD = not __import__('os').environ.get('BTVAE_NO_DGRAD_SUMS')   # reduction pass of the other units' BatchNorm backward in the dX product that forms G
-BWD_FUSED_INTO_CONSUMER = not __import__('os').environ.get('BTVAE_NO_FUSED_BWD')   # ... and run their BatchNorm backward in the epilogue of the last such Linear's dX product
+BWD_SUMS_IN_DGRAD = not os.environ.get('BTVAE_NO_DGRAD_SUMS')   # reduction pass of the other units' BatchNorm backward in the dX product that forms G
+BWD_FUSED_INTO_CONSUMER = not os.environ.get('BTVAE_NO_FUSED_BWD')   # ... and run their BatchNorm backward in the epilogue of the last such Linear's dX product
 
 
-PRESPLIT_WEIGHTS = not __import__('os').environ.get('BTVAE_NO_PRESPLIT')   # split mode: weights split into bf16 planes once per pass
+PRESPLIT_WEIGHTS = not os.environ.get('BTVAE_NO_PRESPLIT')   # split mode: weights split into bf16 planes once per pass
 
 
 def _weight_planes(W: torch.Tensor) -> Optional[torch.Tensor]:
