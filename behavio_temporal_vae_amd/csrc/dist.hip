@@ -6,6 +6,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -164,9 +165,10 @@ __global__ __launch_bounds__(64) void dict_grad_kernel(const float* __restrict__
 // padded with identity).  The matrix stays symmetric through the elimination, so the pivot row a step needs is the
 // pivot COLUMN, one value per lane: each lane drops its value into a per-wave LDS line and the whole row comes back
 // as broadcast 16-byte reads (lane reads cost several times more than these on this chip).  The pivot loop is a
-// real loop over groups of 4 pivots with the register row rotated by 4 per group, so the 4 pivot columns of a group
-// are always registers 0..3 and LDS reads stay 16-byte aligned (the line is stored twice back to back, which turns
-// the rotation's wrap-around into a plain offset).
+// real loop with the register row rotated by one column per step, so the pivot column is always register 0 (the
+// line is stored twice back to back, which turns the rotation's wrap-around into a plain offset, and shifted so
+// that the reads stay 16-byte aligned).  The training path runs the BWD case on mvn_rows_grid_kernel below; this
+// kernel's BWD instantiation remains as the A/B reference (BTVAE_MVN_ROW_PER_LANE=1).
 // BWD: symmetric sweep (A <- -Sigma^-1, pivots = LDL^T pivots so logdet = sum log pivot), alpha = Sigma^-1 (x - mu),
 // P = alpha alpha^T - Sigma^-1.  Outputs: logp; dmu_raw = g*alpha*dfac_mu; Pg packed = g * P * (1 on the diagonal,
 // 2 off it).  !BWD: forward elimination only (half the work): maha = sum y_k^2 / d_k.
@@ -270,6 +272,138 @@ __global__ __launch_bounds__(256) void mvn_rows_kernel(const float* __restrict__
     }
 }
 
+
+// Backward variant on a lane grid.  The 64 lanes of the wave form an 8 x 8 grid; lane (gr, gc) = (lane >> 3, lane & 7)
+// holds the BS x BS block (rows BS*gr.., columns BS*gc..) of the matrix padded to 8*BS with identity.  A sweep step
+// then needs BS values of the pivot column for the block's rows and BS for its columns (the matrix stays symmetric,
+// so the pivot row is the pivot column): the eight lanes that own column k drop it into a per-wave LDS line (one
+// 8-float slot per grid row) and every lane reads two slots back -- 16 + 1 floats per lane and step where the
+// row-per-lane kernel reads the whole row (DP floats), which made that one LDS-bound; all 64 lanes carry FMAs.
+// The pivot loop runs over grid columns kb at run time and over the BS columns inside a block unrolled, so the
+// register that holds column k is static and the owners of column k are a lane predicate (gc == kb).
+// Same sweep, outputs and conventions as mvn_rows_kernel<DP, true>.
+template <int BS>
+__global__ __launch_bounds__(256) void mvn_rows_grid_kernel(const float* __restrict__ Sp, const float* __restrict__ mu,
+                                                            const float* __restrict__ x, const float* __restrict__ dfac_mu,
+                                                            const float* __restrict__ g_rows, float g_const,
+                                                            float* __restrict__ logp, float* __restrict__ dmu_raw,
+                                                            float* __restrict__ Pg, int rows, int B, int D) {
+    static_assert(BS >= 1 && BS <= 8, "block edge of the 8 x 8 lane grid");
+    constexpr int DP = 8 * BS;
+    constexpr int NPMAX = DP * (DP + 1) / 2;
+    __shared__ float sh[4][NPMAX];
+    __shared__ __attribute__((aligned(16))) float line[4][64];      // slot g = floats 8g .. 8g+BS-1
+    __shared__ __attribute__((aligned(16))) float vec[4][64];       // residual, then alpha, same slots
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int gr = lane >> 3, gc = lane & 7;
+    const int row_raw = blockIdx.x * 4 + w;
+    const bool live = row_raw < rows;
+    const int row = live ? row_raw : rows - 1;
+    const int NP = D * (D + 1) / 2;
+    float* ln = line[w];
+    float* vc = vec[w];
+
+    for (int p = lane; p < NP; p += 64) sh[w][p] = Sp[(size_t)row * NP + p];
+    {   // residual of coordinate i = BS*g + r into slot position 8g + r
+        const int g = lane >> 3, r = lane & 7, i = BS * g + r;
+        vc[lane] = (r < BS && i < D) ? x[(size_t)(row % B) * D + i] - mu[(size_t)row * D + i] : 0.f;
+    }
+    __syncthreads();
+
+    // The registers hold the NEGATED sweep matrix (-Sigma at the start, +Sigma^-1 at the end): with c = its pivot
+    // column and rp = 1/pivot, every entry update is a += (c_i * rp) * c_j and the new pivot column is c_i * rp itself,
+    // so no operand needs a sign flip.
+    float a[BS][BS];
+#pragma unroll
+    for (int r = 0; r < BS; ++r)
+#pragma unroll
+        for (int c = 0; c < BS; ++c) {
+            const int i = BS * gr + r, j = BS * gc + c;
+            float v = (i == j) ? 1.f : 0.f;
+            if (i < D && j < D) { const int mx = max(i, j), mn = min(i, j); v = sh[w][mx * (mx + 1) / 2 + mn]; }
+            a[r][c] = -v;
+        }
+
+    float pv = 1.f;                                    // lane k keeps pivot k: one log per lane after the loop
+#pragma unroll 1
+    for (int kb = 0; kb < 8; ++kb) {
+        const bool own_col = gc == kb, own_row = gr == kb;
+#pragma unroll
+        for (int kk = 0; kk < BS; ++kk) {
+            if (own_col) {
+#pragma unroll
+                for (int r = 0; r < BS; ++r) ln[8 * gr + r] = a[r][kk];
+            }
+            __builtin_amdgcn_wave_barrier();
+            float gcol[BS], srow[BS];
+#pragma unroll
+            for (int r = 0; r < BS; ++r) { gcol[r] = ln[8 * gr + r]; srow[r] = ln[8 * gc + r]; }
+            const float piv = -ln[8 * kb + kk];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == kb * BS + kk) pv = piv;
+            float rp = __builtin_amdgcn_rcpf(piv);
+            rp = rp * fmaf(-piv, rp, 2.f);             // one Newton step: relative error of the reciprocal squared
+            float gk[BS];
+#pragma unroll
+            for (int r = 0; r < BS; ++r) gk[r] = gcol[r] * rp;
+            if (own_row) gk[kk] = rp - 1.f;
+#pragma unroll
+            for (int r = 0; r < BS; ++r)
+#pragma unroll
+                for (int c = 0; c < BS; ++c) a[r][c] = fmaf(gk[r], srow[c], a[r][c]);
+            if (own_col) {
+#pragma unroll
+                for (int r = 0; r < BS; ++r) a[r][kk] = gk[r];
+                if (own_row) a[kk][kk] = rp;
+            }
+        }
+    }
+    const float logdet = wave_sum(lane < DP ? logf(pv) : 0.f);
+
+    // a = Sigma^-1.  alpha_i = sum_j a[i][j] r_j: partial over the block's columns, summed over the 8 lanes of a grid row
+    float rv[BS], al[BS];
+#pragma unroll
+    for (int c = 0; c < BS; ++c) rv[c] = vc[8 * gc + c];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < BS; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < BS; ++c) t = fmaf(a[r][c], rv[c], t);
+        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+        al[r] = t;
+    }
+    float mpart = 0.f;                                 // r . alpha, each coordinate once (grid column 0)
+    if (gc == 0) {
+#pragma unroll
+        for (int r = 0; r < BS; ++r) mpart = fmaf(vc[8 * gr + r], al[r], mpart);
+    }
+    const float maha = wave_sum(mpart);
+    __builtin_amdgcn_wave_barrier();
+    if (gc == 0) {
+#pragma unroll
+        for (int r = 0; r < BS; ++r) vc[8 * gr + r] = al[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float ac[BS];
+#pragma unroll
+    for (int c = 0; c < BS; ++c) ac[c] = vc[8 * gc + c];
+
+    const float lp = -0.5f * ((float)D * LOG_2PI + maha) - 0.5f * logdet;
+    if (live && lane == 0) logp[row] = lp;
+    const float g = g_rows ? g_rows[row] : g_const;
+    if (live && lane < D) dmu_raw[(size_t)row * D + lane] = g * vc[8 * (lane / BS) + lane % BS] * dfac_mu[(size_t)row * D + lane];
+    __syncthreads();   // every lane has finished gathering from sh
+#pragma unroll
+    for (int r = 0; r < BS; ++r)
+#pragma unroll
+        for (int c = 0; c < BS; ++c) {
+            const int i = BS * gr + r, j = BS * gc + c;
+            if (i < D && j <= i) sh[w][i * (i + 1) / 2 + j] = g * (al[r] * ac[c] - a[r][c]) * (i == j ? 1.f : 2.f);
+        }
+    __syncthreads();
+    if (live) for (int p = lane; p < NP; p += 64) Pg[(size_t)row * NP + p] = sh[w][p];
+}
 
 // Forward-only variant for D <= 32: two rows per wave (lanes 0..31 and 32..63 each hold one covariance), same
 // elimination; a 24-wide problem otherwise leaves 40 of 64 lanes idle.
@@ -431,6 +565,18 @@ int launch_mvn(int D, const float* Sp, const float* mu, const float* x, const fl
         else if (D <= 24) BTVAE_MVN_PAIR(24);
         else BTVAE_MVN_PAIR(32);
 #undef BTVAE_MVN_PAIR
+        return btvae::check_launch("mvn_rows");
+    }
+    static const bool row_per_lane = getenv("BTVAE_MVN_ROW_PER_LANE") != nullptr;      // A/B switch: the older backward kernel
+    if (BWD && !row_per_lane) {
+#define BTVAE_MVN_GRID(BSV) hipLaunchKernelGGL((mvn_rows_grid_kernel<BSV>), grid, block, 0, s, Sp, mu, x, dfac_mu, g_rows, g_const, logp, dmu_raw, Pg, rows, B, D)
+        if (D <= 8) BTVAE_MVN_GRID(1);
+        else if (D <= 16) BTVAE_MVN_GRID(2);
+        else if (D <= 24) BTVAE_MVN_GRID(3);
+        else if (D <= 32) BTVAE_MVN_GRID(4);
+        else if (D <= 48) BTVAE_MVN_GRID(6);
+        else BTVAE_MVN_GRID(8);
+#undef BTVAE_MVN_GRID
         return btvae::check_launch("mvn_rows");
     }
 #define BTVAE_MVN_CASE(DPV) hipLaunchKernelGGL((mvn_rows_kernel<DPV, BWD>), grid, block, 0, s, Sp, mu, x, dfac_mu, g_rows, g_const, logp, dmu_raw, Pg, rows, B, D)
