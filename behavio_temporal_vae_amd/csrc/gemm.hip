@@ -348,13 +348,15 @@ __global__ __launch_bounds__(256) void cols_finalize_kernel(const float* __restr
 // image F (W rows = output columns, reduction along a row; the forward products): blocks [ceil(R/128)][ceil(C/16)][3][2048],
 // element (row r, k) of a block at s_off(r, k >> 3) + (k & 7); image D (W rows = reduction index; the dX products):
 // blocks [ceil(C/128)][ceil(R/16)][3][2048], element (k row, column) at 128 * row + column.  Zero padded.
-// One thread per 8 consecutive elements of a row, first of image F, then of image D.
+// One thread per 8 consecutive elements of a row, first of image F, then of image D (`which`: bit 0 = F, bit 1 = D).
+template <bool VEC>
 __global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restrict__ W, int ldw, int R, int C,
-                                                            unsigned short* __restrict__ planes) {
+                                                            unsigned short* __restrict__ planes, int which) {
     const int FT = (R + 127) / 128, FK = (C + 15) / 16, DT = (C + 127) / 128, DK = (R + 15) / 16;
     const size_t nF = (size_t)FT * FK * 256, nD = (size_t)DT * DK * 256;
     size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nF + nD) return;
+    if (!(which & 1)) idx += nF;
+    if (idx >= nF + ((which & 2) ? nD : 0)) return;
     int r, c0;
     unsigned short* dst;
     if (idx < nF) {
@@ -370,8 +372,14 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restr
         dst = planes + nF * 24 + blk * (3 * SPLANE) + row * 128 + seg * 8;
     }
     float v[8];
+    if (VEC && r < R && c0 + 7 < C) {
+        const float4 q0 = *reinterpret_cast<const float4*>(W + (size_t)r * ldw + c0);
+        const float4 q1 = *reinterpret_cast<const float4*>(W + (size_t)r * ldw + c0 + 4);
+        v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (r < R && c0 + i < C) ? W[(size_t)r * ldw + c0 + i] : 0.f;
+        for (int i = 0; i < 8; ++i) v[i] = (r < R && c0 + i < C) ? W[(size_t)r * ldw + c0 + i] : 0.f;
+    }
     unsigned H[4], M[4], L[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) split2(v[2 * i], v[2 * i + 1], H[i], M[i], L[i]);
@@ -461,19 +469,24 @@ BTVAE_API int btvae_get_gemm_precision(void) { return g_precision.load(std::memo
 // (btvae_weight_planes) instead of by every workgroup of every product: the *_pw entry points below take the planes
 // next to W and, in the split mode, read the weight operand from them.  The planes are a copy: refresh them whenever
 // W changes.  They hold two tile-ordered images (one for the forward products, one for the dX products), 12 bytes per
-// padded weight element in all; 16-byte aligned base.
+// padded weight element in all; 16-byte aligned base.  `which` selects the images to (re)write: 1 forward, 2 dX, 3 both;
+// a product must only be given planes whose image for its direction is current.
 BTVAE_API long long btvae_weight_planes_elems(int N, int K) {
     if (N <= 0 || K <= 0) return 0;
     return planes_f_elems(N, K) + planes_d_elems(N, K);
 }
 
-BTVAE_API int btvae_weight_planes(const float* W, int ldw, int N, int K, void* planes, void* stream) {
+BTVAE_API int btvae_weight_planes(const float* W, int ldw, int N, int K, void* planes, int which, void* stream) {
     BTVAE_REQUIRE(W && planes, "weight_planes: null pointer");
+    BTVAE_REQUIRE(which >= 1 && which <= 3, "weight_planes: which = %d (1: forward image, 2: dX image, 3: both)", which);
     BTVAE_REQUIRE(N > 0 && K > 0 && ldw >= K, "weight_planes: bad shape N=%d K=%d ldw=%d", N, K, ldw);
     BTVAE_REQUIRE(aligned16(planes), "weight_planes: planes must be 16-byte aligned");
-    const size_t threads = (size_t)(btvae_weight_planes_elems(N, K) / 24);
-    hipLaunchKernelGGL(weight_planes_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       W, ldw, N, K, (unsigned short*)planes);
+    const size_t threads = (size_t)(((which & 1) ? planes_f_elems(N, K) : 0) + ((which & 2) ? planes_d_elems(N, K) : 0)) / 24;
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (ldw % 4 == 0 && aligned16(W))
+        hipLaunchKernelGGL(weight_planes_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, (unsigned short*)planes, which);
+    else
+        hipLaunchKernelGGL(weight_planes_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, (unsigned short*)planes, which);
     return check_launch("weight_planes");
 }
 

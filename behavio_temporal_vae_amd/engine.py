@@ -187,14 +187,18 @@ BWD_FUSED_INTO_CONSUMER = not os.environ.get('BTVAE_NO_FUSED_BWD')   # ... and r
 PRESPLIT_WEIGHTS = not os.environ.get('BTVAE_NO_PRESPLIT')   # split mode: weights split into bf16 planes once per pass
 
 
-def _weight_planes(W: torch.Tensor) -> Optional[torch.Tensor]:
-    """bf16 planes of a weight matrix for the ``*_pw`` products (``btvae_weight_planes``), or None outside the split
-    mode.  They are a copy of ``W`` as it is now: made per forward pass, used by that pass and its backward."""
+PLANES_FWD, PLANES_DX = 1, 2
+
+
+def _weight_planes(W: torch.Tensor, which: int) -> Optional[torch.Tensor]:
+    """bf16 planes of a weight matrix for the ``*_pw`` products (``btvae_weight_planes``; ``which``: the forward image,
+    the dX image or both), or None outside the split mode.  They are a copy of ``W`` as it is now: made per forward
+    pass, used by that pass and its backward."""
     if not PRESPLIT_WEIGHTS or nv.lib().btvae_get_gemm_precision() != 2:
         return None
     N, K = W.shape
     planes = torch.empty(nv.lib().btvae_weight_planes_elems(N, K), dtype=torch.int16, device=W.device)
-    nv.call("btvae_weight_planes", P(W), K, N, K, P(planes))
+    nv.call("btvae_weight_planes", P(W), K, N, K, P(planes), which)
     return planes
 
 
@@ -228,9 +232,10 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
     if x_src is not None:
         x_src.readers += 1
     x, W, b, x_sc, x_sh = _linear_operands(u.lin, x)
-    wp = _weight_planes(W)
     # the dX product of the backward reads the unfolded weight
-    wp_bwd = None if saved is None else (wp if W is u.lin.weight else _weight_planes(u.lin.weight))
+    same = W is u.lin.weight
+    wp = _weight_planes(W, PLANES_FWD | (PLANES_DX if (same and saved is not None) else 0))
+    wp_bwd = None if saved is None else (wp if same else _weight_planes(u.lin.weight, PLANES_DX))
     if u.bn is not None and train:
         if M * (BN_SYNC.world if BN_SYNC is not None else 1) <= 1:
             # torch.nn.BatchNorm1d refuses a one-row batch in train mode (torch/nn/functional.py, _verify_batch_size)
@@ -310,7 +315,7 @@ def head_forward(u: Unit, x, act: int, lo: float, hi: float, want_dfac: bool, wa
     dfac = torch.empty(M, N, device=dev) if want_dfac else None
     sq = torch.empty(M, N, device=dev) if want_sq else None
     nv.call("btvae_linear_head_fwd", P(a), K, P(W), P(b), act, float(lo), float(hi), P(val), P(dfac), P(sq), M, K, N)
-    return val, dfac, sq, (x_sc, x_sh, x_pr), (_weight_planes(u.lin.weight) if want_dfac else None)
+    return val, dfac, sq, (x_sc, x_sh, x_pr), (_weight_planes(u.lin.weight, PLANES_DX) if want_dfac else None)
 
 
 @dataclass

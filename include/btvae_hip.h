@@ -40,10 +40,11 @@ int btvae_get_gemm_precision(void);
  * into `planes`: three bf16 planes [N padded to 16][K padded to 16] (high, middle, low pieces, zero padded, 16-byte
  * aligned base, btvae_weight_planes_elems(N, K) 2-byte elements in all).  The *_pw variants of the forward and dX
  * products take the planes next to W and read the weight operand from them in mode 2 (other modes, unaligned operands
- * and Wplanes == NULL use W as the plain entry points do).  The planes are a copy: call btvae_weight_planes again
- * whenever W has changed. */
+ * and Wplanes == NULL use W as the plain entry points do).  The planes hold one tile-ordered image per direction;
+ * `which` = 1 writes the forward image, 2 the dX image, 3 both, and a product must be given planes whose image for its
+ * direction is current.  The planes are a copy: call btvae_weight_planes again whenever W has changed. */
 long long btvae_weight_planes_elems(int N, int K);
-int btvae_weight_planes(const float* W, int ldw, int N, int K, void* planes, void* stream);
+int btvae_weight_planes(const float* W, int ldw, int N, int K, void* planes, int which, void* stream);
 
 /* ---- Linear layers on MFMA (src/submodels.py:15-17 Linear+ReLU, :20-21 BatchNorm1d, :28-35 NNBlock.forward) ---- */
 /* Y[M,N] = relu(X[M,K] W[N,K]^T + b); stat_partials[ceil(M/128)][2][N] = per-row-tile column (mean, M2). */

@@ -222,7 +222,9 @@ def test_presplit_weight_products(dev, gemm_mode, M, N, K):
     FT, FK, DT, DK = (N + 127) // 128, (K + 15) // 16, (K + 127) // 128, (N + 15) // 16
     assert n_el == (FT * FK + DT * DK) * 3 * 2048
     planes = torch.full((n_el,), 0x7FC0, dtype=torch.int16, device=dev)
-    nv.call("btvae_weight_planes", P(Wd), K, N, K, P(planes))
+    nv.call("btvae_weight_planes", P(Wd), K, N, K, P(planes), 1)
+    assert bool((planes[FT * FK * 3 * 2048:] == 0x7FC0).all()), "which = 1 leaves the dX image alone"
+    nv.call("btvae_weight_planes", P(Wd), K, N, K, P(planes), 2)
     # pieces: h = W truncated to bf16, m = (W - h) truncated, l = (W - h - m) truncated; all differences exact in fp32
     Wp = torch.zeros(max(FT * 128, DK * 16), max(FK * 16, DT * 128), device=dev); Wp[:N, :K] = Wd
     trunc = lambda t: (t.view(torch.int32) & -65536).view(torch.float32)

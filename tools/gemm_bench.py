@@ -34,8 +34,23 @@ def main():
     dW = torch.empty(N, K, device=dev)
     ws = torch.empty(32 * 1024 * 1024, device=dev)
     planes = torch.empty(nv.lib().btvae_weight_planes_elems(N, K), dtype=torch.int16, device=dev)
-    nv.call("btvae_weight_planes", P(W), K, N, K, P(planes))
+    nv.call("btvae_weight_planes", P(W), K, N, K, P(planes), 3)
+    # head-output shapes (reduction over V=100 outputs): epilogue- and HBM-heavy dX product fused with the producing
+    # unit's BatchNorm backward, and the head forward
+    V = 100
+    Wh = torch.randn(V, K, device=dev, generator=g) * 0.03
+    dV = torch.randn(M, V, device=dev, generator=g)
+    hp = torch.empty(nv.lib().btvae_weight_planes_elems(V, K), dtype=torch.int16, device=dev)
+    nv.call("btvae_weight_planes", P(Wh), K, V, K, P(hp), 3)
+    mean, inv, gam, sums = (torch.rand(K, device=dev, generator=g) + 0.5 for _ in range(4))
+    sums2 = torch.randn(2, K, device=dev, generator=g)
+    colpart = torch.empty((M + 127) // 128, K, device=dev)
+    hv, hd, hs = (torch.empty(M, V, device=dev) for _ in range(3))
     ops = {
+        "headout_bnbwd": lambda: nv.call("btvae_linear_dgrad_bnbwd_pw", P(dV), P(Wh), P(hp), None, P(X), P(mean), P(inv), P(gam), P(sums2), M, P(dX), P(colpart), M, V, K),
+        "headout_plain": lambda: nv.call("btvae_linear_dgrad_pw", P(dV), P(Wh), P(hp), None, P(dX), K, M, V, K),
+        "headout_gstats": lambda: nv.call("btvae_linear_dgrad_gstats_pw", P(dV), P(Wh), P(hp), None, P(X), P(mean), P(inv), P(dX), P(part), M, V, K),
+        "head_fwd": lambda: nv.call("btvae_linear_head_fwd", P(X), K, P(Wh), P(b), 2, 1e-4, 0.62, P(hv), P(hd), P(hs), M, K, V),
         "fwd_pw": lambda: nv.call("btvae_linear_relu_stats_fwd_pw", P(X), K, P(W), P(planes), P(b), P(Y), P(part), M, K, N),
         "dgrad_pw": lambda: nv.call("btvae_linear_dgrad_pw", P(Y), P(W), P(planes), None, P(dX), K, M, N, K),
         "fwd": lambda: nv.call("btvae_linear_relu_stats_fwd", P(X), K, P(W), P(b), P(Y), P(part), M, K, N),
