@@ -29,7 +29,9 @@ static thread_local int g_open = -1;
 
 static hipEvent_t get_event() {
     if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
-    hipEvent_t e; hipEventCreate(&e); return e;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return e;
 }
 
 void prof_begin(int kind, hipStream_t s, double flops, double bytes) {
@@ -37,7 +39,12 @@ void prof_begin(int kind, hipStream_t s, double flops, double bytes) {
     if (!((g_kind_mask >> kind) & 1u) || flops < g_min_flops) return;
     std::lock_guard<std::mutex> lk(g_mu);
     ProfRec r{kind, get_event(), get_event(), flops, bytes};
-    hipEventRecord(r.e0, s);
+    if (!r.e0 || !r.e1 || hipEventRecord(r.e0, s) != hipSuccess) {      // timing is best effort: leave this launch untimed
+        (void)hipGetLastError();
+        if (r.e0) g_free.push_back(r.e0);
+        if (r.e1) g_free.push_back(r.e1);
+        return;
+    }
     g_recs.push_back(r);
     g_open = (int)g_recs.size() - 1;
 }
@@ -45,7 +52,11 @@ void prof_begin(int kind, hipStream_t s, double flops, double bytes) {
 void prof_end(int kind, hipStream_t s) {
     if (!g_prof_on || g_open < 0) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    hipEventRecord(g_recs[g_open].e1, s);
+    if (hipEventRecord(g_recs[g_open].e1, s) != hipSuccess) {           // drop the record: its end is unknown
+        (void)hipGetLastError();
+        g_free.push_back(g_recs[g_open].e0); g_free.push_back(g_recs[g_open].e1);
+        g_recs.erase(g_recs.begin() + g_open);
+    }
     g_open = -1;
 }
 
