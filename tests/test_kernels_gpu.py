@@ -367,7 +367,8 @@ def test_reparam_kl(dev, threeD):
     assert abs(e1.mean().item()) < 0.05 and abs(e1.std().item() - 1) < 0.05
 
 
-@pytest.mark.parametrize("D,V,rows,B", [(48, 100, 301, 43), (6, 9, 50, 10), (24, 100, 130, 130), (64, 70, 37, 37), (2, 3, 5, 1), (33, 40, 4, 4)])
+@pytest.mark.parametrize("D,V,rows,B", [(48, 100, 301, 43), (6, 9, 50, 10), (24, 100, 130, 130), (64, 70, 37, 37), (2, 3, 5, 1), (33, 40, 4, 4),
+                                         (12, 20, 70, 7), (30, 35, 66, 66)])
 def test_dictgauss_mvn(dev, D, V, rows, B):
     U = rnd(D, V, seed=1)
     sig = (rnd(rows, V, seed=2).abs() * 0.3 + 1e-3).clamp(max=0.62)
