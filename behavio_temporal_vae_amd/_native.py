@@ -31,6 +31,7 @@ _SIGS = {
     "btvae_linear_relu_affine_fwd": [P, I, P, P, P, P, P, P, I, I, I, P],
     "btvae_linear_relu_affine_fwd_pw": [P, I, P, P, P, P, P, P, P, I, I, I, P],
     "btvae_weight_planes": [P, I, I, I, P, I, P],
+    "btvae_weight_planes_multi": [P, P, P, P, P, I, P],
     "btvae_linear_head_fwd": [P, I, P, P, I, F, F, P, P, P, I, I, I, P],
     "btvae_linear_dgrad": [P, P, P, P, I, I, I, I, P],
     "btvae_linear_dgrad_pw": [P, P, P, P, P, I, I, I, I, P],

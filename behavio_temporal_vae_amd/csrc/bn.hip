@@ -17,8 +17,9 @@ __device__ __forceinline__ double group_sum8(double v) {
 }
 
 // ---- train-mode statistics: merge the per-row-tile (mean, M2) partials of the GEMM epilogue ----
-// A workgroup owns 8 groups of VEC columns; thread (group g = tid & 7, part = tid >> 3) takes every 32nd tile, so a
-// 512-tile merge is 16 independent loads per thread.  With n_t rows in tile t the merged moments are
+// A workgroup owns one group of VEC columns; thread t takes every 256th tile (a 512-tile merge is two independent
+// 16-byte load pairs per thread, 250 workgroups at N=1000: the merge is latency-bound, so it is spread wide).  With
+// n_t rows in tile t the merged moments are
 //   mean = sum n_t mean_t / n,   M2 = sum M2_t + sum n_t mean_t^2 - n mean^2
 // accumulated in fp64 (inputs are fp32, so the subtraction keeps ~29 bits more than they carry).
 template <int VEC>
@@ -27,42 +28,40 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
                                                                 float* __restrict__ m2_out,
                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                 float momentum, float eps) {
-    __shared__ double sh[3][4][8 * VEC];
-    const int g = threadIdx.x & 7, part = threadIdx.x >> 3, w = threadIdx.x >> 6;
-    const int c0 = (blockIdx.x * 8 + g) * VEC;
+    __shared__ double sh[3][4][VEC];
+    const int w = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * VEC;
     double s1[VEC], s2[VEC], q[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { s1[j] = 0.0; s2[j] = 0.0; q[j] = 0.0; }
-    if (c0 < N) {
-#pragma unroll 4
-        for (int t = part; t < ntiles; t += 32) {
-            const double nb = (double)min(tile_rows, M - t * tile_rows);
-            float mb[VEC], qb[VEC];
-            if (VEC == 4) {
-                const float4 a = *reinterpret_cast<const float4*>(partials + ((size_t)t * 2 + 0) * N + c0);
-                const float4 b = *reinterpret_cast<const float4*>(partials + ((size_t)t * 2 + 1) * N + c0);
-                mb[0] = a.x; mb[VEC > 1 ? 1 : 0] = a.y; mb[VEC > 2 ? 2 : 0] = a.z; mb[VEC > 3 ? 3 : 0] = a.w;
-                qb[0] = b.x; qb[VEC > 1 ? 1 : 0] = b.y; qb[VEC > 2 ? 2 : 0] = b.z; qb[VEC > 3 ? 3 : 0] = b.w;
-            } else {
-                mb[0] = partials[((size_t)t * 2 + 0) * N + c0];
-                qb[0] = partials[((size_t)t * 2 + 1) * N + c0];
-            }
+#pragma unroll 2
+    for (int t = threadIdx.x; t < ntiles; t += 256) {
+        const double nb = (double)min(tile_rows, M - t * tile_rows);
+        float mb[VEC], qb[VEC];
+        if (VEC == 4) {
+            const float4 a = *reinterpret_cast<const float4*>(partials + ((size_t)t * 2 + 0) * N + c0);
+            const float4 b = *reinterpret_cast<const float4*>(partials + ((size_t)t * 2 + 1) * N + c0);
+            mb[0] = a.x; mb[VEC > 1 ? 1 : 0] = a.y; mb[VEC > 2 ? 2 : 0] = a.z; mb[VEC > 3 ? 3 : 0] = a.w;
+            qb[0] = b.x; qb[VEC > 1 ? 1 : 0] = b.y; qb[VEC > 2 ? 2 : 0] = b.z; qb[VEC > 3 ? 3 : 0] = b.w;
+        } else {
+            mb[0] = partials[((size_t)t * 2 + 0) * N + c0];
+            qb[0] = partials[((size_t)t * 2 + 1) * N + c0];
+        }
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const double m = (double)mb[j];
-                s1[j] += nb * m; s2[j] += nb * m * m; q[j] += (double)qb[j];
-            }
+        for (int j = 0; j < VEC; ++j) {
+            const double m = (double)mb[j];
+            s1[j] += nb * m; s2[j] += nb * m * m; q[j] += (double)qb[j];
         }
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        s1[j] = group_sum8(s1[j]); s2[j] = group_sum8(s2[j]); q[j] = group_sum8(q[j]);
-        if ((threadIdx.x & 63) < 8) { sh[0][w][g * VEC + j] = s1[j]; sh[1][w][g * VEC + j] = s2[j]; sh[2][w][g * VEC + j] = q[j]; }
+        s1[j] = wave_sum_d(s1[j]); s2[j] = wave_sum_d(s2[j]); q[j] = wave_sum_d(q[j]);
+        if ((threadIdx.x & 63) == 0) { sh[0][w][j] = s1[j]; sh[1][w][j] = s2[j]; sh[2][w][j] = q[j]; }
     }
     __syncthreads();
     const int cl = threadIdx.x;
-    const int c = blockIdx.x * 8 * VEC + cl;
-    if (cl >= 8 * VEC || c >= N) return;
+    const int c = c0 + cl;
+    if (cl >= VEC || c >= N) return;
     const double n = (double)M;
     const double a1 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
     const double a2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
@@ -419,9 +418,9 @@ void colsum_finalize(hipStream_t s, const float* partials, int nchunks, int nvec
 void stats_finalize(hipStream_t s, const float* partials, int ntiles, int tile_rows, int M, int N, float* mean, float* invstd, float* m2,
                     float* running_mean, float* running_var, float momentum, float eps) {
     if (part_vec4(N, partials))
-        hipLaunchKernelGGL((bn_stats_finalize_kernel<4>), dim3((N + 31) / 32), dim3(256), 0, s, partials, ntiles, tile_rows, M, N, mean, invstd, m2, running_mean, running_var, momentum, eps);
+        hipLaunchKernelGGL((bn_stats_finalize_kernel<4>), dim3((N + 3) / 4), dim3(256), 0, s, partials, ntiles, tile_rows, M, N, mean, invstd, m2, running_mean, running_var, momentum, eps);
     else
-        hipLaunchKernelGGL((bn_stats_finalize_kernel<1>), dim3((N + 7) / 8), dim3(256), 0, s, partials, ntiles, tile_rows, M, N, mean, invstd, m2, running_mean, running_var, momentum, eps);
+        hipLaunchKernelGGL((bn_stats_finalize_kernel<1>), dim3(N), dim3(256), 0, s, partials, ntiles, tile_rows, M, N, mean, invstd, m2, running_mean, running_var, momentum, eps);
 }
 
 }  // namespace

@@ -349,12 +349,10 @@ __global__ __launch_bounds__(256) void cols_finalize_kernel(const float* __restr
 // element (row r, k) of a block at s_off(r, k >> 3) + (k & 7); image D (W rows = reduction index; the dX products):
 // blocks [ceil(C/128)][ceil(R/16)][3][2048], element (k row, column) at 128 * row + column.  Zero padded.
 // One thread per 8 consecutive elements of a row, first of image F, then of image D (`which`: bit 0 = F, bit 1 = D).
-template <bool VEC>
-__global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restrict__ W, int ldw, int R, int C,
-                                                            unsigned short* __restrict__ planes, int which) {
+__device__ __forceinline__ void weight_planes_body(const float* __restrict__ W, int ldw, int R, int C,
+                                                   unsigned short* __restrict__ planes, int which, bool vec, size_t idx) {
     const int FT = (R + 127) / 128, FK = (C + 15) / 16, DT = (C + 127) / 128, DK = (R + 15) / 16;
     const size_t nF = (size_t)FT * FK * 256, nD = (size_t)DT * DK * 256;
-    size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (!(which & 1)) idx += nF;
     if (idx >= nF + ((which & 2) ? nD : 0)) return;
     int r, c0;
@@ -372,7 +370,7 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restr
         dst = planes + nF * 24 + blk * (3 * SPLANE) + row * 128 + seg * 8;
     }
     float v[8];
-    if (VEC && r < R && c0 + 7 < C) {
+    if (vec && r < R && c0 + 7 < C) {
         const float4 q0 = *reinterpret_cast<const float4*>(W + (size_t)r * ldw + c0);
         const float4 q1 = *reinterpret_cast<const float4*>(W + (size_t)r * ldw + c0 + 4);
         v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
@@ -386,6 +384,22 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restr
     *reinterpret_cast<uint4*>(dst) = make_uint4(H[0], H[1], H[2], H[3]);
     *reinterpret_cast<uint4*>(dst + SPLANE) = make_uint4(M[0], M[1], M[2], M[3]);
     *reinterpret_cast<uint4*>(dst + 2 * SPLANE) = make_uint4(L[0], L[1], L[2], L[3]);
+}
+
+__global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restrict__ W, int ldw, int R, int C,
+                                                            unsigned short* __restrict__ planes, int which, int vec) {
+    weight_planes_body(W, ldw, R, C, planes, which, vec != 0, (size_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// several matrices in one launch: blockIdx.y selects the entry
+constexpr int PLANES_BATCH = 16;
+struct PlanesBatch {
+    const float* W[PLANES_BATCH]; unsigned short* planes[PLANES_BATCH];
+    int ldw[PLANES_BATCH], R[PLANES_BATCH], C[PLANES_BATCH], which[PLANES_BATCH], vec[PLANES_BATCH];
+};
+__global__ __launch_bounds__(256) void weight_planes_multi_kernel(const PlanesBatch b) {
+    const int e = blockIdx.y;
+    weight_planes_body(b.W[e], b.ldw[e], b.R[e], b.C[e], b.planes[e], b.which[e], b.vec[e] != 0, (size_t)blockIdx.x * 256 + threadIdx.x);
 }
 
 inline long long planes_f_elems(int N, int K) { return (long long)((N + 127) / 128) * ((K + 15) / 16) * 3 * SPLANE; }
@@ -483,11 +497,31 @@ BTVAE_API int btvae_weight_planes(const float* W, int ldw, int N, int K, void* p
     BTVAE_REQUIRE(aligned16(planes), "weight_planes: planes must be 16-byte aligned");
     const size_t threads = (size_t)(((which & 1) ? planes_f_elems(N, K) : 0) + ((which & 2) ? planes_d_elems(N, K) : 0)) / 24;
     const dim3 grid((unsigned)((threads + 255) / 256));
-    if (ldw % 4 == 0 && aligned16(W))
-        hipLaunchKernelGGL(weight_planes_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, (unsigned short*)planes, which);
-    else
-        hipLaunchKernelGGL(weight_planes_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, (unsigned short*)planes, which);
+    hipLaunchKernelGGL(weight_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, (unsigned short*)planes, which,
+                       (ldw % 4 == 0 && aligned16(W)) ? 1 : 0);
     return check_launch("weight_planes");
+}
+
+// The same for `count` matrices (host arrays of length count, matrices contiguous with row pitch K[i]) in one launch
+// per 16 of them: the weights of a whole network at the start of a pass.
+BTVAE_API int btvae_weight_planes_multi(const float* const* W, const int* N, const int* K, void* const* planes, const int* which,
+                                        int count, void* stream) {
+    BTVAE_REQUIRE(W && N && K && planes && which && count > 0, "weight_planes_multi: bad arguments");
+    for (int base = 0; base < count; base += PLANES_BATCH) {
+        PlanesBatch b{};
+        const int n = std::min(PLANES_BATCH, count - base);
+        size_t most = 0;
+        for (int i = 0; i < n; ++i) {
+            const int j = base + i;
+            BTVAE_REQUIRE(W[j] && planes[j] && aligned16(planes[j]), "weight_planes_multi: entry %d: null or unaligned pointer", j);
+            BTVAE_REQUIRE(N[j] > 0 && K[j] > 0 && which[j] >= 1 && which[j] <= 3, "weight_planes_multi: entry %d: bad shape or image selection", j);
+            b.W[i] = W[j]; b.planes[i] = (unsigned short*)planes[j]; b.ldw[i] = K[j]; b.R[i] = N[j]; b.C[i] = K[j]; b.which[i] = which[j];
+            b.vec[i] = (K[j] % 4 == 0 && aligned16(W[j])) ? 1 : 0;
+            most = std::max(most, (size_t)(((which[j] & 1) ? planes_f_elems(N[j], K[j]) : 0) + ((which[j] & 2) ? planes_d_elems(N[j], K[j]) : 0)) / 24);
+        }
+        hipLaunchKernelGGL(weight_planes_multi_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, b);
+    }
+    return check_launch("weight_planes_multi");
 }
 
 namespace {

@@ -202,6 +202,33 @@ def _weight_planes(W: torch.Tensor, which: int) -> Optional[torch.Tensor]:
     return planes
 
 
+def _plan_planes(plan: "NetPlan", backward: bool) -> Dict[torch.nn.Linear, torch.Tensor]:
+    """bf16 planes of every Linear weight of a network in one launch (``btvae_weight_planes_multi``) at the start of a
+    pass: hidden Linears get the forward image (+ the dX image when a backward follows), head output Linears the dX
+    image only (their forward kernel reads the fp32 weight).  Empty outside the split mode."""
+    if not PRESPLIT_WEIGHTS or nv.lib().btvae_get_gemm_precision() != 2:
+        return {}
+    items = [(u.lin, PLANES_FWD | (PLANES_DX if backward else 0)) for u in plan.trunk]
+    for units in plan.heads.values():
+        items += [(u.lin, PLANES_FWD | (PLANES_DX if backward else 0)) for u in units[:-1]]
+        if backward:
+            items.append((units[-1].lin, PLANES_DX))
+    L = nv.lib()
+    sizes = [L.btvae_weight_planes_elems(lin.out_features, lin.in_features) for lin, _ in items]
+    buf = torch.empty(sum(sizes), dtype=torch.int16, device=items[0][0].weight.device)
+    out, off = {}, 0
+    for (lin, _), n in zip(items, sizes):
+        out[lin] = buf[off:off + n]           # every size is a multiple of 6144 elements: slices stay 16-byte aligned
+        off += n
+    cnt = len(items)
+    PtrArr, IntArr = nv.c_void_p * cnt, nv.ctypes.c_int * cnt
+    nv.call("btvae_weight_planes_multi",
+            PtrArr(*[lin.weight.data_ptr() for lin, _ in items]), IntArr(*[lin.out_features for lin, _ in items]),
+            IntArr(*[lin.in_features for lin, _ in items]), PtrArr(*[out[lin].data_ptr() for lin, _ in items]),
+            IntArr(*[w for _, w in items]), cnt)
+    return out
+
+
 def _linear_operands(lin: torch.nn.Linear, x):
     """(A, W, b, scale, shift) of ``lin`` applied to ``x``: a tensor as is, a Normed input through folded weights."""
     if not isinstance(x, Normed):
@@ -216,10 +243,12 @@ def _linear_operands(lin: torch.nn.Linear, x):
     return x.y, Wf, bf, sc, sh
 
 
-def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_normed: bool = False):
+def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_normed: bool = False,
+                 planes: Optional[Dict[torch.nn.Linear, torch.Tensor]] = None):
     """One Linear->ReLU->BatchNorm(->+x) unit (src/submodels.py:15-21,30-33) or a bare Linear.  ``x`` may be a
     ``Normed`` (train mode, non-residual units).  With ``keep_normed`` the caller promises that every consumer of
-    the result is a plain (non-residual) Linear, and a BatchNorm unit without dropout returns a ``Normed``."""
+    the result is a plain (non-residual) Linear, and a BatchNorm unit without dropout returns a ``Normed``.
+    ``planes``: pre-split weights of the network made at the start of the pass (``_plan_planes``)."""
     M, K = x.shape
     N = u.lin.out_features
     dev = x.device
@@ -234,8 +263,13 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
     x, W, b, x_sc, x_sh = _linear_operands(u.lin, x)
     # the dX product of the backward reads the unfolded weight
     same = W is u.lin.weight
-    wp = _weight_planes(W, PLANES_FWD | (PLANES_DX if (same and saved is not None) else 0))
-    wp_bwd = None if saved is None else (wp if same else _weight_planes(u.lin.weight, PLANES_DX))
+    own = planes.get(u.lin) if planes else None            # planes of the unfolded weight, made with the rest of the network's
+    if same:
+        wp = own if own is not None else _weight_planes(W, PLANES_FWD | (PLANES_DX if saved is not None else 0))
+        wp_bwd = wp if saved is not None else None
+    else:
+        wp = _weight_planes(W, PLANES_FWD)
+        wp_bwd = None if saved is None else (own if own is not None else _weight_planes(u.lin.weight, PLANES_DX))
     if u.bn is not None and train:
         if M * (BN_SYNC.world if BN_SYNC is not None else 1) <= 1:
             # torch.nn.BatchNorm1d refuses a one-row batch in train mode (torch/nn/functional.py, _verify_batch_size)
@@ -298,7 +332,8 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
     return out
 
 
-def head_forward(u: Unit, x, act: int, lo: float, hi: float, want_dfac: bool, want_sq: bool):
+def head_forward(u: Unit, x, act: int, lo: float, hi: float, want_dfac: bool, want_sq: bool,
+                 planes: Optional[Dict[torch.nn.Linear, torch.Tensor]] = None):
     """Head output Linear fused with its clamp / softplus / relu non-linearity
     (src/submodels.py:102-104,156-157).  ``x`` may be a ``Normed``.
     Returns (value, dfac or None, value^2 or None, (scale, shift, by-product holder) of a Normed input or Nones,
@@ -315,7 +350,8 @@ def head_forward(u: Unit, x, act: int, lo: float, hi: float, want_dfac: bool, wa
     dfac = torch.empty(M, N, device=dev) if want_dfac else None
     sq = torch.empty(M, N, device=dev) if want_sq else None
     nv.call("btvae_linear_head_fwd", P(a), K, P(W), P(b), act, float(lo), float(hi), P(val), P(dfac), P(sq), M, K, N)
-    return val, dfac, sq, (x_sc, x_sh, x_pr), (_weight_planes(u.lin.weight, PLANES_DX) if want_dfac else None)
+    own = planes.get(u.lin) if planes else None
+    return val, dfac, sq, (x_sc, x_sh, x_pr), ((own if own is not None else _weight_planes(u.lin.weight, PLANES_DX)) if want_dfac else None)
 
 
 @dataclass
@@ -335,12 +371,13 @@ def net_forward(plan: NetPlan, x: torch.Tensor, train: bool, tape: Optional[NetT
     # if that is not residual, the first unit of every head for the trunk's last unit, the head's output Linear
     h = x
     nt = len(plan.trunk)
+    planes = _plan_planes(plan, tape is not None)
     for i, u in enumerate(plan.trunk):
         if i + 1 < nt:
             normed_ok = not plan.trunk[i + 1].residual
         else:
             normed_ok = all(not units[0].residual for units in plan.heads.values())
-        h = unit_forward(u, h, train, tape.trunk if tape is not None else None, keep_normed=train and normed_ok)
+        h = unit_forward(u, h, train, tape.trunk if tape is not None else None, keep_normed=train and normed_ok, planes=planes)
     out, sqs = {}, {}
     for name, units in plan.heads.items():
         t = h
@@ -348,9 +385,9 @@ def net_forward(plan: NetPlan, x: torch.Tensor, train: bool, tape: Optional[NetT
         hidden = units[:-1]
         for i, u in enumerate(hidden):
             normed_ok = i + 1 == len(hidden) or not hidden[i + 1].residual
-            t = unit_forward(u, t, train, sv, keep_normed=train and normed_ok)
+            t = unit_forward(u, t, train, sv, keep_normed=train and normed_ok, planes=planes)
         act, lo, hi = head_specs[name]
-        val, dfac, sq, affine, planes = head_forward(units[-1], t, act, lo, hi, tape is not None, name in want_sq)
+        val, dfac, sq, affine, hplanes = head_forward(units[-1], t, act, lo, hi, tape is not None, name in want_sq, planes)
         out[name] = val
         if sq is not None:
             sqs[name] = sq
@@ -359,7 +396,7 @@ def net_forward(plan: NetPlan, x: torch.Tensor, train: bool, tape: Optional[NetT
             tape.head_in[name] = t.y if isinstance(t, Normed) else t
             tape.head_in_affine[name] = affine
             tape.dfac[name] = dfac
-            tape.head_planes[name] = planes
+            tape.head_planes[name] = hplanes
     return out, sqs
 
 

@@ -45,6 +45,9 @@ int btvae_get_gemm_precision(void);
  * direction is current.  The planes are a copy: call btvae_weight_planes again whenever W has changed. */
 long long btvae_weight_planes_elems(int N, int K);
 int btvae_weight_planes(const float* W, int ldw, int N, int K, void* planes, int which, void* stream);
+/* The same for `count` contiguous matrices W[i][N[i]][K[i]] (host arrays of length count) in one launch per 16 entries. */
+int btvae_weight_planes_multi(const float* const* W, const int* N, const int* K, void* const* planes, const int* which,
+                              int count, void* stream);
 
 /* ---- Linear layers on MFMA (src/submodels.py:15-17 Linear+ReLU, :20-21 BatchNorm1d, :28-35 NNBlock.forward) ---- */
 /* Y[M,N] = relu(X[M,K] W[N,K]^T + b); stat_partials[ceil(M/128)][2][N] = per-row-tile column (mean, M2). */

@@ -271,6 +271,26 @@ def test_presplit_weight_products(dev, gemm_mode, M, N, K):
         assert torch.equal(D0, D1) and torch.equal(g0, g1), "dgrad + BatchNorm backward sums"
 
 
+def test_weight_planes_batch(dev):
+    """Planes of several matrices in one launch equal the one-matrix calls, image selection included."""
+    import ctypes
+    shapes = [(1000, 52), (1000, 1000), (48, 1000), (100, 72), (36, 33)] * 4          # 20 entries: two launches of <= 16
+    which = [(i % 3) + 1 for i in range(len(shapes))]
+    Ws = [rnd(n, k, seed=60 + i).float().to(dev) for i, (n, k) in enumerate(shapes)]
+    L = nv.lib()
+    sizes = [L.btvae_weight_planes_elems(n, k) for n, k in shapes]
+    one = [torch.full((s,), 0x7FC0, dtype=torch.int16, device=dev) for s in sizes]
+    many = [torch.full((s,), 0x7FC0, dtype=torch.int16, device=dev) for s in sizes]
+    for W, (n, k), pl, wh in zip(Ws, shapes, one, which):
+        nv.call("btvae_weight_planes", P(W), k, n, k, P(pl), wh)
+    cnt = len(shapes)
+    PA, IA = ctypes.c_void_p * cnt, ctypes.c_int * cnt
+    nv.call("btvae_weight_planes_multi", PA(*[W.data_ptr() for W in Ws]), IA(*[n for n, _ in shapes]), IA(*[k for _, k in shapes]),
+            PA(*[pl.data_ptr() for pl in many]), IA(*which), cnt)
+    for i, (a, b) in enumerate(zip(one, many)):
+        assert torch.equal(a, b), f"entry {i}"
+
+
 def test_matmul_bias_and_mul(dev):
     M, K, N = 260, 100, 1176
     A, B, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
