@@ -10,12 +10,6 @@ namespace {
 
 constexpr int STRIP_COLS = 256;   // columns per workgroup: 64 lanes x float4
 
-// Sum over the lanes that hold the same column group (lane bits 3..5) of a wave.
-__device__ __forceinline__ double group_sum8(double v) {
-    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-    return v;
-}
-
 // ---- train-mode statistics: merge the per-row-tile (mean, M2) partials of the GEMM epilogue ----
 // A workgroup owns one group of VEC columns; thread t takes every 256th tile (a 512-tile merge is two independent
 // 16-byte load pairs per thread, 250 workgroups at N=1000: the merge is latency-bound, so it is spread wide).  With
@@ -235,30 +229,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // merge [nchunks][NVEC][N] partial column sums in fp64; raw_k (if given) = sum, out_k (if given) (+)= sum.
-// Same thread layout as the statistics merge: 8 groups of VEC columns x 32 chunk-parts per workgroup.
+// Same thread layout as the statistics merge: one group of VEC columns per workgroup, thread t takes every 256th chunk.
 template <int VEC, int NVEC>
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partials, int nchunks, int N,
                                                               float* out0, float* out1, float* raw0, float* raw1, int accumulate) {
-    __shared__ double sh[NVEC][4][8 * VEC];
-    const int g = threadIdx.x & 7, part = threadIdx.x >> 3, w = threadIdx.x >> 6;
-    const int c0 = (blockIdx.x * 8 + g) * VEC;
+    __shared__ double sh[NVEC][4][VEC];
+    const int w = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * VEC;
     double s[NVEC][VEC];
 #pragma unroll
     for (int k = 0; k < NVEC; ++k)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) s[k][j] = 0.0;
-    if (c0 < N) {
-#pragma unroll 4
-        for (int t = part; t < nchunks; t += 32) {
+#pragma unroll 2
+    for (int t = threadIdx.x; t < nchunks; t += 256) {
 #pragma unroll
-            for (int k = 0; k < NVEC; ++k) {
-                const float* src = partials + ((size_t)t * NVEC + k) * N + c0;
-                if (VEC == 4) {
-                    const float4 a = *reinterpret_cast<const float4*>(src);
-                    s[k][0] += a.x; s[k][VEC > 1 ? 1 : 0] += a.y; s[k][VEC > 2 ? 2 : 0] += a.z; s[k][VEC > 3 ? 3 : 0] += a.w;
-                } else {
-                    s[k][0] += src[0];
-                }
+        for (int k = 0; k < NVEC; ++k) {
+            const float* src = partials + ((size_t)t * NVEC + k) * N + c0;
+            if (VEC == 4) {
+                const float4 a = *reinterpret_cast<const float4*>(src);
+                s[k][0] += a.x; s[k][VEC > 1 ? 1 : 0] += a.y; s[k][VEC > 2 ? 2 : 0] += a.z; s[k][VEC > 3 ? 3 : 0] += a.w;
+            } else {
+                s[k][0] += src[0];
             }
         }
     }
@@ -266,13 +258,13 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     for (int k = 0; k < NVEC; ++k)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const double v = group_sum8(s[k][j]);
-            if ((threadIdx.x & 63) < 8) sh[k][w][g * VEC + j] = v;
+            const double v = wave_sum_d(s[k][j]);
+            if ((threadIdx.x & 63) == 0) sh[k][w][j] = v;
         }
     __syncthreads();
     const int cl = threadIdx.x;
-    const int c = blockIdx.x * 8 * VEC + cl;
-    if (cl >= 8 * VEC || c >= N) return;
+    const int c = c0 + cl;
+    if (cl >= VEC || c >= N) return;
 #pragma unroll
     for (int k = 0; k < NVEC; ++k) {
         const float v = (float)(sh[k][0][cl] + sh[k][1][cl] + sh[k][2][cl] + sh[k][3][cl]);
@@ -405,7 +397,7 @@ inline bool part_vec4(int N, const void* p) { return N % 4 == 0 && (reinterpret_
 void colsum_finalize(hipStream_t s, const float* partials, int nchunks, int nvec, int N, float* out0, float* out1, float* raw0,
                      float* raw1, int accumulate) {
     const bool v4 = part_vec4(N, partials);
-    const dim3 grid((N + (v4 ? 32 : 8) - 1) / (v4 ? 32 : 8)), block(256);
+    const dim3 grid(v4 ? (N + 3) / 4 : N), block(256);
     if (nvec == 2) {
         if (v4) hipLaunchKernelGGL((colsum_finalize_kernel<4, 2>), grid, block, 0, s, partials, nchunks, N, out0, out1, raw0, raw1, accumulate);
         else    hipLaunchKernelGGL((colsum_finalize_kernel<1, 2>), grid, block, 0, s, partials, nchunks, N, out0, out1, raw0, raw1, accumulate);
