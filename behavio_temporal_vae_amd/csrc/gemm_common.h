@@ -272,9 +272,26 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             }
         }
         __syncthreads();
-        // LDS image -> global, 16 bytes per lane: thread t handles columns 4*(t&31).. of local rows (t>>5) + 8j
+        // LDS image -> global, 16 bytes per lane: thread t handles columns 4*(t&31).. of local rows (t>>5) + 8j.
+        // EPI_GSTATS stores each row before it reads that row's BatchNorm input, and a load that follows a store in
+        // program order cannot be waited for without waiting for the store too (one in-order counter): there the
+        // add-in and BatchNorm-input loads of all eight rows are issued first (measured: -15 % on a skinny product;
+        // the same hoisting makes the other epilogues slower, so they load row by row).
         const int c4 = (tid & 31) << 2;
         const int col = n0 + c4;
+        constexpr bool HOIST = EPI == EPI_GSTATS;
+        float4 rq[HOIST ? 8 : 1], yq[HOIST ? 8 : 1];
+        if (HOIST) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int lr = (tid >> 5) + 8 * j;
+                const int row = m0 + (lr >> 5) * 64 + rb * 32 + (lr & 31);
+                if (row < p.M && col < p.N) {
+                    rq[j] = p.R ? ld4(p.R + (size_t)row * p.ldr + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    yq[j] = ld4(p.bn_y + (size_t)row * p.ldc + col);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int lr = (tid >> 5) + 8 * j;
@@ -288,9 +305,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
                 } else if (EPI == EPI_RELU_STATS) {
                     st4(Cz + o, v);
                 } else if (EPI == EPI_GSTATS) {
-                    if (p.R) { const float4 q = ld4(p.R + (size_t)row * p.ldr + col); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+                    { const float4 q = rq[j]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
                     st4(Cz + o, v);
-                    const float4 y = ld4(p.bn_y + o);
+                    const float4 y = yq[j];
                     bsb[0] += v.x; bsb[1] += v.y; bsb[2] += v.z; bsb[3] += v.w;
                     bk0[0] = fmaf(v.x, (y.x - bmu[0]) * bis[0], bk0[0]); bk0[1] = fmaf(v.y, (y.y - bmu[1]) * bis[1], bk0[1]);
                     bk0[2] = fmaf(v.z, (y.z - bmu[2]) * bis[2], bk0[2]); bk0[3] = fmaf(v.w, (y.w - bmu[3]) * bis[3], bk0[3]);

@@ -50,6 +50,8 @@ def main():
         "headout_bnbwd": lambda: nv.call("btvae_linear_dgrad_bnbwd_pw", P(dV), P(Wh), P(hp), None, P(X), P(mean), P(inv), P(gam), P(sums2), M, P(dX), P(colpart), M, V, K),
         "headout_plain": lambda: nv.call("btvae_linear_dgrad_pw", P(dV), P(Wh), P(hp), None, P(dX), K, M, V, K),
         "headout_gstats": lambda: nv.call("btvae_linear_dgrad_gstats_pw", P(dV), P(Wh), P(hp), None, P(X), P(mean), P(inv), P(dX), P(part), M, V, K),
+        "gstats_big": lambda: nv.call("btvae_linear_dgrad_gstats_pw", P(Y), P(W), P(planes), P(X), P(X), P(mean), P(inv), P(dX), P(part), M, N, K),
+        "bnbwd_big": lambda: nv.call("btvae_linear_dgrad_bnbwd_pw", P(Y), P(W), P(planes), P(X), P(X), P(mean), P(inv), P(gam), P(sums2), M, P(dX), P(colpart), M, N, K),
         "head_fwd": lambda: nv.call("btvae_linear_head_fwd", P(X), K, P(Wh), P(b), 2, 1e-4, 0.62, P(hv), P(hd), P(hs), M, K, V),
         "fwd_pw": lambda: nv.call("btvae_linear_relu_stats_fwd_pw", P(X), K, P(W), P(planes), P(b), P(Y), P(part), M, K, N),
         "dgrad_pw": lambda: nv.call("btvae_linear_dgrad_pw", P(Y), P(W), P(planes), None, P(dX), K, M, N, K),
