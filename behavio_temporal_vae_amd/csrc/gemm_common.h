@@ -273,22 +273,38 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
         }
         __syncthreads();
         // LDS image -> global, 16 bytes per lane: thread t handles columns 4*(t&31).. of local rows (t>>5) + 8j.
-        // EPI_GSTATS stores each row before it reads that row's BatchNorm input, and a load that follows a store in
-        // program order cannot be waited for without waiting for the store too (one in-order counter): there the
-        // add-in and BatchNorm-input loads of all eight rows are issued first (measured: -15 % on a skinny product;
-        // the same hoisting makes the other epilogues slower, so they load row by row).
+        // Everything the eight rows need from global memory (add-in, BatchNorm input, multipliers) is loaded first:
+        // a load that follows a store in program order cannot be waited for without waiting for the store too (one
+        // in-order counter), so loads issued row by row between the stores each cost a full memory round trip.  The
+        // loads are branch-free (rows / columns past the edge read a clamped, valid address): inside per-row
+        // branches the same hoisting is slower than no hoisting.
         const int c4 = (tid & 31) << 2;
         const int col = n0 + c4;
-        constexpr bool HOIST = EPI == EPI_GSTATS;
-        float4 rq[HOIST ? 8 : 1], yq[HOIST ? 8 : 1];
-        if (HOIST) {
+        constexpr bool USE_R = EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_RELU_AFFINE || EPI == EPI_GSTATS || EPI == EPI_BNBWD;
+        constexpr bool USE_Y = EPI == EPI_GSTATS || EPI == EPI_BNBWD;
+        constexpr bool USE_E = EPI == EPI_MUL;
+        float4 rq[USE_R ? 8 : 1], yq[USE_Y ? 8 : 1], eq1[USE_E ? 8 : 1], eq2[USE_E ? 8 : 1];
+        {
+            const int colc = min(col, p.N - 4);
+            int rowc[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int lr = (tid >> 5) + 8 * j;
-                const int row = m0 + (lr >> 5) * 64 + rb * 32 + (lr & 31);
-                if (row < p.M && col < p.N) {
-                    rq[j] = p.R ? ld4(p.R + (size_t)row * p.ldr + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    yq[j] = ld4(p.bn_y + (size_t)row * p.ldc + col);
+                rowc[j] = min(m0 + (lr >> 5) * 64 + rb * 32 + (lr & 31), p.M - 1);
+            }
+            if (USE_Y) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) yq[j] = ld4(p.bn_y + (size_t)rowc[j] * p.ldc + colc);
+            }
+            if (USE_R && p.R) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rq[j] = ld4(p.R + (size_t)rowc[j] * p.ldr + colc);
+            }
+            if (USE_E) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    eq1[j] = ld4(p.E1 + (size_t)rowc[j] * p.lde + colc);
+                    eq2[j] = ld4(p.E2 + (size_t)rowc[j] * p.lde + colc);
                 }
             }
         }
@@ -299,21 +315,19 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             if (row < p.M && col < p.N) {          // N % 4 == 0 on this path: a 4-column group is in or out as a whole
                 float4 v = ld4(lds + lr * EPL + c4);
                 const size_t o = (size_t)row * p.ldc + col;
+                if (USE_R && p.R) { const float4 q = rq[j]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
                 if (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_RELU_AFFINE) {
-                    if (p.R) { const float4 q = ld4(p.R + (size_t)row * p.ldr + col); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
                     st4(Cz + o, v);
                 } else if (EPI == EPI_RELU_STATS) {
                     st4(Cz + o, v);
                 } else if (EPI == EPI_GSTATS) {
-                    { const float4 q = rq[j]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
                     st4(Cz + o, v);
                     const float4 y = yq[j];
                     bsb[0] += v.x; bsb[1] += v.y; bsb[2] += v.z; bsb[3] += v.w;
                     bk0[0] = fmaf(v.x, (y.x - bmu[0]) * bis[0], bk0[0]); bk0[1] = fmaf(v.y, (y.y - bmu[1]) * bis[1], bk0[1]);
                     bk0[2] = fmaf(v.z, (y.z - bmu[2]) * bis[2], bk0[2]); bk0[3] = fmaf(v.w, (y.w - bmu[3]) * bis[3], bk0[3]);
                 } else if (EPI == EPI_BNBWD) {
-                    if (p.R) { const float4 q = ld4(p.R + (size_t)row * p.ldr + col); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-                    const float4 y = ld4(p.bn_y + o);
+                    const float4 y = yq[j];
                     float4 d;
                     d.x = y.x > 0.f ? bk0[0] * v.x - bk1[0] - bk2[0] * ((y.x - bmu[0]) * bis[0]) : 0.f;
                     d.y = y.y > 0.f ? bk0[1] * v.y - bk1[1] - bk2[1] * ((y.y - bmu[1]) * bis[1]) : 0.f;
@@ -322,8 +336,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
                     st4(Cz + o, d);
                     bsb[0] += d.x; bsb[1] += d.y; bsb[2] += d.z; bsb[3] += d.w;
                 } else if (EPI == EPI_MUL) {
-                    const size_t e = (size_t)row * p.lde + col;
-                    const float4 a = ld4(p.E1 + e), b = ld4(p.E2 + e);
+                    const float4 a = eq1[j], b = eq2[j];
                     st4(Cz + o, make_float4(v.x * a.x * b.x, v.y * a.y * b.y, v.z * a.z * b.z, v.w * a.w * b.w));
                 } else if (EPI == EPI_HEAD) {
                     const float raw[4] = {v.x, v.y, v.z, v.w};
