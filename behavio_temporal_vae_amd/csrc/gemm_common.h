@@ -308,57 +308,69 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
                 }
             }
         }
+        // one output row (local row lr, global row `row`) of this thread's four columns
+        auto emit = [&](int j, int lr, int row) {
+            float4 v = ld4(lds + lr * EPL + c4);
+            const size_t o = (size_t)row * p.ldc + col;
+            if (USE_R && p.R) { const float4 q = rq[j]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            if (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_RELU_AFFINE) {
+                st4(Cz + o, v);
+            } else if (EPI == EPI_RELU_STATS) {
+                st4(Cz + o, v);
+            } else if (EPI == EPI_GSTATS) {
+                st4(Cz + o, v);
+                const float4 y = yq[j];
+                bsb[0] += v.x; bsb[1] += v.y; bsb[2] += v.z; bsb[3] += v.w;
+                bk0[0] = fmaf(v.x, (y.x - bmu[0]) * bis[0], bk0[0]); bk0[1] = fmaf(v.y, (y.y - bmu[1]) * bis[1], bk0[1]);
+                bk0[2] = fmaf(v.z, (y.z - bmu[2]) * bis[2], bk0[2]); bk0[3] = fmaf(v.w, (y.w - bmu[3]) * bis[3], bk0[3]);
+            } else if (EPI == EPI_BNBWD) {
+                const float4 y = yq[j];
+                float4 d;
+                d.x = y.x > 0.f ? bk0[0] * v.x - bk1[0] - bk2[0] * ((y.x - bmu[0]) * bis[0]) : 0.f;
+                d.y = y.y > 0.f ? bk0[1] * v.y - bk1[1] - bk2[1] * ((y.y - bmu[1]) * bis[1]) : 0.f;
+                d.z = y.z > 0.f ? bk0[2] * v.z - bk1[2] - bk2[2] * ((y.z - bmu[2]) * bis[2]) : 0.f;
+                d.w = y.w > 0.f ? bk0[3] * v.w - bk1[3] - bk2[3] * ((y.w - bmu[3]) * bis[3]) : 0.f;
+                st4(Cz + o, d);
+                bsb[0] += d.x; bsb[1] += d.y; bsb[2] += d.z; bsb[3] += d.w;
+            } else if (EPI == EPI_MUL) {
+                const float4 a = eq1[j], b = eq2[j];
+                st4(Cz + o, make_float4(v.x * a.x * b.x, v.y * a.y * b.y, v.z * a.z * b.z, v.w * a.w * b.w));
+            } else if (EPI == EPI_HEAD) {
+                const float raw[4] = {v.x, v.y, v.z, v.w};
+                float val[4], df[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int lr = (tid >> 5) + 8 * j;
-            const int row = m0 + (lr >> 5) * 64 + rb * 32 + (lr & 31);
-            if (row < p.M && col < p.N) {          // N % 4 == 0 on this path: a 4-column group is in or out as a whole
-                float4 v = ld4(lds + lr * EPL + c4);
-                const size_t o = (size_t)row * p.ldc + col;
-                if (USE_R && p.R) { const float4 q = rq[j]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-                if (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_RELU_AFFINE) {
-                    st4(Cz + o, v);
-                } else if (EPI == EPI_RELU_STATS) {
-                    st4(Cz + o, v);
-                } else if (EPI == EPI_GSTATS) {
-                    st4(Cz + o, v);
-                    const float4 y = yq[j];
-                    bsb[0] += v.x; bsb[1] += v.y; bsb[2] += v.z; bsb[3] += v.w;
-                    bk0[0] = fmaf(v.x, (y.x - bmu[0]) * bis[0], bk0[0]); bk0[1] = fmaf(v.y, (y.y - bmu[1]) * bis[1], bk0[1]);
-                    bk0[2] = fmaf(v.z, (y.z - bmu[2]) * bis[2], bk0[2]); bk0[3] = fmaf(v.w, (y.w - bmu[3]) * bis[3], bk0[3]);
-                } else if (EPI == EPI_BNBWD) {
-                    const float4 y = yq[j];
-                    float4 d;
-                    d.x = y.x > 0.f ? bk0[0] * v.x - bk1[0] - bk2[0] * ((y.x - bmu[0]) * bis[0]) : 0.f;
-                    d.y = y.y > 0.f ? bk0[1] * v.y - bk1[1] - bk2[1] * ((y.y - bmu[1]) * bis[1]) : 0.f;
-                    d.z = y.z > 0.f ? bk0[2] * v.z - bk1[2] - bk2[2] * ((y.z - bmu[2]) * bis[2]) : 0.f;
-                    d.w = y.w > 0.f ? bk0[3] * v.w - bk1[3] - bk2[3] * ((y.w - bmu[3]) * bis[3]) : 0.f;
-                    st4(Cz + o, d);
-                    bsb[0] += d.x; bsb[1] += d.y; bsb[2] += d.z; bsb[3] += d.w;
-                } else if (EPI == EPI_MUL) {
-                    const float4 a = eq1[j], b = eq2[j];
-                    st4(Cz + o, make_float4(v.x * a.x * b.x, v.y * a.y * b.y, v.z * a.z * b.z, v.w * a.w * b.w));
-                } else if (EPI == EPI_HEAD) {
-                    const float raw[4] = {v.x, v.y, v.z, v.w};
-                    float val[4], df[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (p.act == 0) {            // clamp
-                            val[e] = fminf(fmaxf(raw[e], p.lo), p.hi);
-                            df[e] = (raw[e] >= p.lo && raw[e] <= p.hi) ? 1.f : 0.f;
-                        } else if (p.act == 1) {     // clamp(softplus(raw; threshold 5))
-                            const float sp = softplus5(raw[e]);
-                            val[e] = fminf(fmaxf(sp, p.lo), p.hi);
-                            df[e] = (sp >= p.lo && sp <= p.hi) ? (raw[e] > 5.f ? 1.f : 1.f / (1.f + expf(-raw[e]))) : 0.f;
-                        } else {                     // clamp(relu(raw))
-                            const float rl = fmaxf(raw[e], 0.f);
-                            val[e] = fminf(fmaxf(rl, p.lo), p.hi);
-                            df[e] = (raw[e] > 0.f && rl >= p.lo && rl <= p.hi) ? 1.f : 0.f;
-                        }
+                for (int e = 0; e < 4; ++e) {
+                    if (p.act == 0) {            // clamp
+                        val[e] = fminf(fmaxf(raw[e], p.lo), p.hi);
+                        df[e] = (raw[e] >= p.lo && raw[e] <= p.hi) ? 1.f : 0.f;
+                    } else if (p.act == 1) {     // clamp(softplus(raw; threshold 5))
+                        const float sp = softplus5(raw[e]);
+                        val[e] = fminf(fmaxf(sp, p.lo), p.hi);
+                        df[e] = (sp >= p.lo && sp <= p.hi) ? (raw[e] > 5.f ? 1.f : 1.f / (1.f + expf(-raw[e]))) : 0.f;
+                    } else {                     // clamp(relu(raw))
+                        const float rl = fmaxf(raw[e], 0.f);
+                        val[e] = fminf(fmaxf(rl, p.lo), p.hi);
+                        df[e] = (raw[e] > 0.f && rl >= p.lo && rl <= p.hi) ? 1.f : 0.f;
                     }
-                    st4(Cz + o, make_float4(val[0], val[1], val[2], val[3]));
-                    if (p.C2) st4(p.C2 + o, make_float4(df[0], df[1], df[2], df[3]));
-                    if (p.C3) st4(p.C3 + o, make_float4(val[0] * val[0], val[1] * val[1], val[2] * val[2], val[3] * val[3]));
+                }
+                st4(Cz + o, make_float4(val[0], val[1], val[2], val[3]));
+                if (p.C2) st4(p.C2 + o, make_float4(df[0], df[1], df[2], df[3]));
+                if (p.C3) st4(p.C3 + o, make_float4(val[0] * val[0], val[1] * val[1], val[2] * val[2], val[3] * val[3]));
+            }
+        };
+        if (col < p.N) {                               // N % 4 == 0 on this path: a 4-column group is in or out as a whole
+            if (m0 + BM <= p.M) {                      // interior row tile (uniform): no per-row checks
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int lr = (tid >> 5) + 8 * j;
+                    emit(j, lr, m0 + (lr >> 5) * 64 + rb * 32 + (lr & 31));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int lr = (tid >> 5) + 8 * j;
+                    const int row = m0 + (lr >> 5) * 64 + rb * 32 + (lr & 31);
+                    if (row < p.M) emit(j, lr, row);
                 }
             }
         }
