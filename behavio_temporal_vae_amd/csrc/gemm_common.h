@@ -3,6 +3,7 @@
 // of a tile = row (r&3)+8(r>>2)+4*(lane>>5), column lane&31), so one epilogue serves both.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -247,30 +248,43 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
         }
     }
 
+    // EPI_RELU_STATS on a row tile that lies inside the matrix (uniform): every row counts, so the statistics need no
+    // per-element bounds test -- the first element is the shift, the count is a constant (invalid columns get count 0)
+    const bool rows_full = EPI == EPI_RELU_STATS && m0 + BM <= p.M;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         // registers -> LDS image; local row = wr*32 + (r&3) + 8(r>>2) + 4*lh
+        auto to_lds = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int col = n0 + wc * 64 + cb * 32 + li;
+            for (int cb = 0; cb < 2; ++cb) {
+                const int col = n0 + wc * 64 + cb * 32 + li;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lr = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float v = acc[rb][cb][r];
-                if (EPI == EPI_BIAS || EPI == EPI_HEAD) v += bias[cb];
-                if (EPI == EPI_RELU_STATS) {
-                    v = fmaxf(v + bias[cb], 0.f);
-                    const int row = m0 + (lr >> 5) * 64 + rb * 32 + (lr & 31);
-                    if (row < p.M && col < p.N) {
-                        if (!have[cb]) { st_k[cb] = v; have[cb] = true; }
-                        const float d = v - st_k[cb];
-                        st_s[cb] += d; st_q[cb] = fmaf(d, d, st_q[cb]); st_c[cb] += 1.f;
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float v = acc[rb][cb][r];
+                    if (EPI == EPI_BIAS || EPI == EPI_HEAD) v += bias[cb];
+                    if (EPI == EPI_RELU_STATS) {
+                        v = fmaxf(v + bias[cb], 0.f);
+                        if (FULL) {
+                            if (rb == 0 && r == 0) st_k[cb] = v;
+                            const float d = v - st_k[cb];
+                            st_s[cb] += d; st_q[cb] = fmaf(d, d, st_q[cb]);
+                        } else {
+                            const int row = m0 + (lr >> 5) * 64 + rb * 32 + (lr & 31);
+                            if (row < p.M && col < p.N) {
+                                if (!have[cb]) { st_k[cb] = v; have[cb] = true; }
+                                const float d = v - st_k[cb];
+                                st_s[cb] += d; st_q[cb] = fmaf(d, d, st_q[cb]); st_c[cb] += 1.f;
+                            }
+                        }
                     }
+                    if (EPI == EPI_RELU_AFFINE) v = fmaxf(v + bias[cb], 0.f) * sc[cb] + sh[cb];
+                    lds[lr * EPL + wc * 64 + cb * 32 + li] = v;
                 }
-                if (EPI == EPI_RELU_AFFINE) v = fmaxf(v + bias[cb], 0.f) * sc[cb] + sh[cb];
-                lds[lr * EPL + wc * 64 + cb * 32 + li] = v;
             }
-        }
+        };
+        if (rows_full) to_lds(std::true_type{}); else to_lds(std::false_type{});
         __syncthreads();
         // LDS image -> global, 16 bytes per lane: thread t handles columns 4*(t&31).. of local rows (t>>5) + 8j.
         // Everything the eight rows need from global memory (add-in, BatchNorm input, multipliers) is loaded first:
@@ -411,6 +425,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
         // per lane (count, mean, M2) -> merge lane halves -> merge the two wave rows through LDS -> one thread per column
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
+            if (rows_full) st_c[cb] = (n0 + wc * 64 + cb * 32 + li < p.N) ? 32.f : 0.f;    // 2 halves x 16 rows per lane
             float cnt = st_c[cb], mean = 0.f, m2 = 0.f;
             if (cnt > 0.f) { mean = st_k[cb] + st_s[cb] / cnt; m2 = fmaxf(st_q[cb] - st_s[cb] * st_s[cb] / cnt, 0.f); }
             const float on = __shfl_xor(cnt, 32, 64), om = __shfl_xor(mean, 32, 64), o2 = __shfl_xor(m2, 32, 64);
