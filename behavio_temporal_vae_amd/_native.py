@@ -137,7 +137,15 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
+# torch.cuda.current_stream() builds a Stream object per call (several microseconds); a training step makes ~120
+# library calls, so the raw handle is read through the same C entry points torch itself uses, when they exist.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr():
+    if _raw_stream is not None and _cur_device is not None:
+        return c_void_p(_raw_stream(_cur_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
