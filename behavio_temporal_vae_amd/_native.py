@@ -62,6 +62,7 @@ _SIGS = {
     "btvae_sample_error_update": [P, P, P, P, I, I, I, I, P],
     "btvae_dirichlet_sample": [P, P, P, I, I, I, I, I, ULL, ULL, P],
     "btvae_colsum": [P, P, P, P, I, I, I, P],
+    "btvae_colsum_noalloc": [P, P, P, I, I, I, P],
     "btvae_reparam_kl_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, ULL, ULL, P],
     "btvae_reparam_kl_bwd": [P, P, P, P, P, P, P, P, I, I, I, I, F, P],
     "btvae_diag_gauss_loglik": [P, P, P, P, P, P, P, P, P, F, I, I, I, P],
@@ -87,6 +88,7 @@ _RET = {
     "btvae_strip_chunks": (c_int, [I]),
     "btvae_bn_relu_bwd_scratch": (c_longlong, [I, I]),
     "btvae_weight_planes_elems": (c_longlong, [I, I]),
+    "btvae_colsum_noalloc_max_floats": (c_longlong, []),
 }
 EXPORTS = sorted(list(_SIGS) + list(_RET))
 PROF_KINDS = ["gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_mvn", "bn", "mvn_rows", "reduce", "optim"]
@@ -111,15 +113,24 @@ def lib():
     return _lib
 
 
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def last_error() -> str:
     return lib().btvae_last_error().decode("utf-8", "replace")
 
 
 def ensure_device(device: torch.device):
-    """Bind the library to ``device`` (checks that it is a gfx950 part) once per device index."""
+    """Set the library up on ``device`` (checks that it is a gfx950 part) once per device index, and require that it
+    is torch's current device: every library call launches on the current device's current stream, so tensors of
+    another device would be read through the wrong device's queue."""
     if device.type != "cuda":
         raise RuntimeError(f"behavio_temporal_vae_amd computes on MI355X only; got tensors on '{device}'")
-    idx = device.index if device.index is not None else torch.cuda.current_device()
+    cur = _cur_device() if _cur_device is not None else torch.cuda.current_device()
+    idx = device.index if device.index is not None else cur
+    if idx != cur:
+        raise RuntimeError(f"tensors are on cuda:{idx} but the current device is cuda:{cur}; wrap the call in "
+                           f"`with torch.cuda.device({idx}):` or call torch.cuda.set_device({idx})")
     if idx not in _inited:
         rc = lib().btvae_init(idx)
         if rc != 0:
@@ -140,7 +151,6 @@ def ptr(t):
 # torch.cuda.current_stream() builds a Stream object per call (several microseconds); a training step makes ~120
 # library calls, so the raw handle is read through the same C entry points torch itself uses, when they exist.
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-_cur_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 def stream_ptr():
@@ -166,8 +176,9 @@ GEMM_PRECISIONS = {"fp32": 0, "bf16": 1, "fp32_split": 2}
 
 
 def set_gemm_precision(name: str):
-    """Operand precision of the Linear-layer products: ``"fp32"`` (default) or ``"bf16"`` (bf16 operands, fp32
-    accumulation).  Process-wide."""
+    """Operand precision of the Linear-layer products, process-wide: ``"fp32_split"`` (what models ask for unless
+    configured otherwise: fp32-accurate products as three-way bf16 splits on the bf16 matrix pipe), ``"fp32"`` (the fp32
+    MFMA instruction; the library's own start-up mode) or ``"bf16"`` (bf16-rounded operands, fp32 accumulation)."""
     if name not in GEMM_PRECISIONS:
         raise ValueError(f"unknown GEMM precision {name!r}; choose from {sorted(GEMM_PRECISIONS)}")
     if lib().btvae_set_gemm_precision(GEMM_PRECISIONS[name]) != 0:

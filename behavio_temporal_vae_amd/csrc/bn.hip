@@ -623,3 +623,58 @@ BTVAE_API int btvae_colsum(const float* G, float* out, float* cur, float* scratc
     colsum_finalize(s, scratch, chunks, 1, N, out, (float*)nullptr, cur, (float*)nullptr, accumulate);
     return check_launch("colsum");
 }
+
+
+// ---- column sums for callers that cannot allocate -------------------------------------------------------------------
+// btvae_colsum needs btvae_strip_chunks(M) * N floats of workspace from the caller.  Code under HIP graph capture, a tight
+// serving loop or a harness that forbids allocation cannot provide one, so the variant below keeps the strip partials in a
+// file-scope device array instead.  Every GPU the library runs on holds its own 4 MiB copy until the process ends.
+namespace {
+constexpr int NOALLOC_MAX_DEVICES = 64;
+constexpr long long NOALLOC_SCRATCH_FLOATS = 1LL << 20;          // 256 row chunks x 4096 columns
+}
+static __device__ __align__(256) float scratch[NOALLOC_SCRATCH_FLOATS];
+namespace {
+float* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};                  // per device: that device's address of `scratch`
+}
+
+namespace btvae {
+// Resolve the device address of `scratch` on the CURRENT device (btvae_init calls this with `device` selected).
+int noalloc_scratch_setup(int device) {
+    BTVAE_REQUIRE(device >= 0 && device < NOALLOC_MAX_DEVICES, "noalloc scratch: device %d beyond the %d this library tracks", device, NOALLOC_MAX_DEVICES);
+    if (g_scratch_ptr[device]) return 0;
+    float* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    BTVAE_REQUIRE(e == hipSuccess && ptr != nullptr, "noalloc scratch: hipGetSymbolAddress failed on device %d: %s", device, hipGetErrorString(e));
+    g_scratch_ptr[device] = ptr;
+    return 0;
+}
+}  // namespace btvae
+
+// btvae_colsum without a workspace argument and without any allocation: the strip partials go to this GPU's copy of the
+// library's static scratch array.  btvae_strip_chunks(M) * N must not exceed btvae_colsum_noalloc_max_floats().  Calls
+// on one GPU share that array: two calls that overlap on different streams of the same GPU race; calls on one stream
+// do not (every call overwrites all the partials it later reads, so nothing needs clearing between calls).
+BTVAE_API long long btvae_colsum_noalloc_max_floats(void) { return NOALLOC_SCRATCH_FLOATS; }
+
+BTVAE_API int btvae_colsum_noalloc(const float* G, float* out, float* cur, int M, int N, int accumulate, void* stream) {
+    BTVAE_REQUIRE(G && (out || cur), "colsum_noalloc: null pointer");
+    BTVAE_REQUIRE(M > 0 && N > 0, "colsum_noalloc: empty problem (M=%d, N=%d)", M, N);
+    const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
+    BTVAE_REQUIRE((long long)chunks * N <= NOALLOC_SCRATCH_FLOATS,
+                  "colsum_noalloc: %d row chunks x %d columns = %lld floats of partials exceed the static scratch of %lld floats; use btvae_colsum with a workspace",
+                  chunks, N, (long long)chunks * N, NOALLOC_SCRATCH_FLOATS);
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    BTVAE_REQUIRE(e == hipSuccess && dev >= 0 && dev < NOALLOC_MAX_DEVICES, "colsum_noalloc: no current device (%s)", hipGetErrorString(e));
+    float* ptr = g_scratch_ptr[dev];
+    BTVAE_REQUIRE(ptr != nullptr, "colsum_noalloc: btvae_init(%d) has not run on the current device", dev);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PK_BN, s, 0, 4.0 * M * N);
+    if (vec4_ok(N, G, nullptr, nullptr, nullptr))
+        hipLaunchKernelGGL((colsum_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, ptr, M, N, rpc);
+    else
+        hipLaunchKernelGGL((colsum_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, ptr, M, N, rpc);
+    colsum_finalize(s, ptr, chunks, 1, N, out, (float*)nullptr, cur, (float*)nullptr, accumulate);
+    return check_launch("colsum_noalloc");
+}

@@ -60,6 +60,8 @@ void prof_end(int kind, hipStream_t s) {
     g_open = -1;
 }
 
+int noalloc_scratch_setup(int device);     // bn.hip: device address of the static scratch array on the current device
+
 }  // namespace btvae
 
 using namespace btvae;
@@ -67,7 +69,8 @@ using namespace btvae;
 BTVAE_API const char* btvae_last_error(void) { return err_buf(); }
 BTVAE_API int btvae_version(void) { return 100; }
 
-// Select `device` and verify it is a gfx950 part; every other entry point assumes this was called.
+// Verify that `device` is a gfx950 part and set up the library's per-device state on it; every other entry point assumes
+// this was called for the device it runs on.  The caller's current device is left as it was.
 BTVAE_API int btvae_init(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -77,9 +80,14 @@ BTVAE_API int btvae_init(int device) {
     e = hipGetDeviceProperties(&prop, device);
     BTVAE_REQUIRE(e == hipSuccess, "btvae_init: hipGetDeviceProperties failed: %s", hipGetErrorString(e));
     BTVAE_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "btvae_init: device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
+    int prev = -1;
+    e = hipGetDevice(&prev);
+    BTVAE_REQUIRE(e == hipSuccess, "btvae_init: hipGetDevice failed: %s", hipGetErrorString(e));
     e = hipSetDevice(device);
     BTVAE_REQUIRE(e == hipSuccess, "btvae_init: hipSetDevice failed: %s", hipGetErrorString(e));
-    return 0;
+    const int rc = noalloc_scratch_setup(device);
+    if (prev != device) (void)hipSetDevice(prev);
+    return rc;
 }
 
 // Turn event timing of kernel families on/off; turning it on clears earlier records.

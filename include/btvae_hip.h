@@ -16,7 +16,8 @@ extern "C" {
 /* ---- library state ---- */
 const char* btvae_last_error(void);
 int btvae_version(void);
-/* Select `device` and verify it is gfx950.  Call once per device before anything else. */
+/* Verify that `device` is gfx950 and set up the library's per-device state on it.  Call once per device before anything
+ * else.  The caller's current device is left unchanged; every other call runs on the device that is current. */
 int btvae_init(int device);
 /* Event timing per kernel family (0 gemm_fwd, 1 gemm_dgrad, 2 gemm_wgrad, 3 gemm_mvn, 4 bn, 5 mvn_rows,
  * 6 reduce, 7 optim); collect after a device synchronisation into arrays of 8. */
@@ -134,6 +135,13 @@ int btvae_relu_bwd(const float* G, const float* Y, const unsigned char* keep, fl
  * The backward entry points above take the same optional `dbias_cur`: this call's bias gradient regardless of
  * `accumulate`, which btvae_linear_wgrad_affine needs. */
 int btvae_colsum(const float* G, float* out, float* cur, float* scratch, int M, int N, int accumulate, void* stream);
+/* btvae_colsum for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  No counterpart in the reference.  Takes no workspace and allocates nothing: the strip partials live in a
+ * static 4 MiB device array inside the library, one copy per GPU, whose address btvae_init(device) resolves.  Rejects
+ * btvae_strip_chunks(M) * N > btvae_colsum_noalloc_max_floats() (1,048,576).  All calls on one GPU share the array: calls
+ * that overlap on different streams of the same GPU race; successive calls on one stream are safe. */
+long long btvae_colsum_noalloc_max_floats(void);
+int btvae_colsum_noalloc(const float* G, float* out, float* cur, int M, int N, int accumulate, void* stream);
 /* A Linear[N,K] fed by a train-mode BatchNorm (src/submodels.py:15-21 followed by the next block's Linear, :30-34,
  * :63-68) computes (Y*sc + sh) W^T + b = Y (W*sc)^T + (b + W sh): Wf, bf are those weights, sc/sh[K] the BatchNorm's
  * column scale and shift.  The normalised activation is then never written; the weight gradient follows from Y by
