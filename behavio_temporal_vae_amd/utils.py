@@ -6,10 +6,7 @@ kernels instead.
 from __future__ import annotations
 
 import argparse
-import json
 import math
-import os
-import sys
 
 import numpy as np
 import torch
@@ -20,12 +17,7 @@ def to_positive(xtilde):
     return torch.nn.functional.softplus(xtilde, beta=1, threshold=5)
 
 
-def from_positive(x):
-    return x + torch.log(-torch.expm1(-x))
-
-
 to_sigma = to_positive
-from_sigma = from_positive
 
 
 def matrix_normalizer(matrix):
@@ -111,28 +103,6 @@ class DirichletTransformer:
         raise NotImplementedError
 
 
-class MinMaxTransformer:
-    def __init__(self, feature_range=(0, 1)):
-        self.feature_range = feature_range
-
-    def fit(self, X):
-        lo, hi = self.feature_range
-        self.data_min_, self.data_max_ = np.min(X, axis=0), np.max(X, axis=0)
-        self.data_range_ = self.data_max_ - self.data_min_
-        self.scale_ = (hi - lo) / self.data_range_
-        self.min_ = lo - self.data_min_ * self.scale_
-        return self
-
-    def transform(self, X):
-        return np.clip(X * self.scale_ + self.min_, self.feature_range[0], self.feature_range[1])
-
-    def inverse_transform(self, X):
-        return np.clip((X - self.min_) / self.scale_, self.data_min_, self.data_max_)
-
-    def fit_transform(self, X):
-        return self.fit(X).transform(X)
-
-
 # ----- training utilities (src/utils.py:156-215) -----
 class EarlyStopping:
     """Stops after ``patience`` validations that fail to beat the best score by more than ``delta``
@@ -160,34 +130,6 @@ class EarlyStopping:
             say("Early stopping initiated.")
 
 
-def find_matching_model(base_dir, user_config_dict):
-    for subdir, _, _ in os.walk(base_dir):
-        path = os.path.join(subdir, 'user_config_dict.json')
-        if os.path.exists(path):
-            with open(path, 'r') as f:
-                if json.load(f) == user_config_dict:
-                    return subdir
-    return None
-
-
-def get_latest_path(base_dir):
-    paths = [os.path.join(base_dir, f) for f in os.listdir(base_dir)]
-    return paths[int(np.argmax([os.path.getmtime(f) for f in paths]))]
-
-
-def flatten_dict(nested_dict, parent_key='', sep='_'):
-    flat = {}
-    for k, v in nested_dict.items():
-        key = f"{parent_key}{sep}{k}" if parent_key else k
-        if isinstance(v, dict):
-            flat.update(flatten_dict(v, key, sep=sep))
-        elif isinstance(v, list):
-            flat[key] = json.dumps(v)
-        else:
-            flat[key] = v
-    return flat
-
-
 def str2bool(v):
     if isinstance(v, bool):
         return v
@@ -197,11 +139,3 @@ def str2bool(v):
     if s in ('no', 'false', 'f', 'n', '0'):
         return False
     raise argparse.ArgumentTypeError('Boolean value expected.')
-
-
-def blockPrint():
-    sys.stdout = open(os.devnull, 'w')
-
-
-def enablePrint():
-    sys.stdout = sys.__stdout__

@@ -85,9 +85,11 @@ class FusedClipAdam(torch.optim.Optimizer):
         self._adam: Optional[E.ClipAdam] = None
 
     def zero_grad(self, set_to_none: bool = True):
-        # gradients are overwritten (not accumulated) by every backward pass; keep the arena views alive
-        if not set_to_none:
-            self.model._grad_arena.zero_()
+        """Zero the gradient arena in both modes and keep the parameters' ``.grad`` views alive.  The fused
+        ``train_core`` overwrites gradients and does not need this, but the module-level idiom of the reference
+        (``forward`` -> ``zero_grad(set_to_none=True)`` -> ``loss.backward()`` -> ``step()``, src/vae_models.py:319-324)
+        accumulates into the arena through autograd, so the buffers must start at zero: one 42 MB memset."""
+        self.model._grad_arena.zero_()
 
     def _ensure(self):
         arena = self.model._arena
@@ -139,8 +141,9 @@ class VAE(torch.nn.Module):
         self._arena = None
         self._grad_arena = None
         self._dp_world = 1
-        # operand precision of the Linear products: "fp32" (the reference's arithmetic) or "bf16"; an extra
-        # keyword of the model config, swallowed by the reference's constructors like any other unknown key
+        # operand precision of the Linear products: "fp32_split" (default; fp32-accurate on the bf16 matrix pipe), "fp32"
+        # (the fp32 MFMA instruction) or "bf16"; an extra keyword of the model config, swallowed by the reference's
+        # constructors like any other unknown key
         self.gemm_precision = DEFAULT_GEMM_PRECISION
         self.set_gemm_precision(_.get("gemm_precision", DEFAULT_GEMM_PRECISION))
         self._finish_init()

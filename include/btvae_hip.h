@@ -5,7 +5,8 @@
  * reference op sequence (file:line under the reference root) it replaces.  All pointers are DEVICE
  * pointers to contiguous row-major fp32 arrays unless stated; `stream` is a hipStream_t.  Every function
  * returns 0 on success, non-zero on failure with the reason in btvae_last_error().  Nothing here
- * allocates or frees device memory or synchronises the device.
+ * allocates or frees device memory or synchronises the device; the optional event timing (btvae_prof_enable) creates
+ * HIP events on first use and recycles them.
  */
 #ifndef BTVAE_HIP_H
 #define BTVAE_HIP_H
@@ -28,8 +29,9 @@ int btvae_prof_collect(double* ms, double* flops, double* bytes, long long* laun
 /* Before btvae_prof_collect: the launches of one family with the largest FLOP count (its dominant shape). */
 int btvae_prof_dominant(int kind, double* ms, double* flops_per_launch, long long* count);
 
-/* Operand precision of the matrix products.  0 = the fp32 MFMA instruction (default of the library; the precision
- * torch.nn.Linear runs at in the reference, src/submodels.py:15-17).  1 = operands of the Linear-layer products
+/* Operand precision of the matrix products.  0 = the fp32 MFMA instruction (the mode the library starts in; the
+ * precision torch.nn.Linear runs at in the reference, src/submodels.py:15-17; the Python host mirror selects mode 2
+ * unless a model is configured otherwise).  1 = operands of the Linear-layer products
  * (btvae_linear_*_fwd, _dgrad, _wgrad) rounded to bf16 on the way into LDS, fp32 accumulation; the covariance products
  * stay fp32.  2 = every product fp32-accurate on the bf16 matrix pipe: operands split exactly into three bf16 pieces,
  * six bf16 MFMAs per product (error against fp64 at or below mode 0's).  Process-wide. */

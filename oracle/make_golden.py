@@ -64,7 +64,7 @@ def synth_profiles(n, d, rng):
 
 
 def np_state(sd):
-    return {"sd::" + k: v.detach().cpu().numpy() for k, v in sd.items()}
+    return {"sd::" + k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
 
 
 class Cdim:
@@ -423,6 +423,185 @@ def case_imputation_mh(name="imputation_mh_tiny", seed=21, N=9, D=6, W=3, T_pg=2
           "accept rate", float((u < rho).mean()), "margin", margin)
 
 
+class ListLoader:
+    """A loader that yields fixed [x, c] batches; ``dataset`` only has to have the right length
+    (src/vae_models.py:196,331,336 iterate the loader and read ``len(loader.dataset)``)."""
+    def __init__(self, batches, n):
+        self.batches, self.dataset = batches, range(n)
+        self.batch_sampler = types.SimpleNamespace(batch_size=batches[0][0].shape[0])     # read for the progress bar only (:176)
+        self.drop_last = True
+
+    def __iter__(self):
+        return iter([[x, c] for x, c in self.batches])
+
+
+def _warm_bn(model, D, rng, calls=3):
+    model.train()
+    with torch.no_grad():
+        for _ in range(calls):
+            model.forward(torch.tensor(synth_profiles(16, D, rng)), torch.tensor(rng.normal(size=(16, 4)).astype(np.float32)), num_mc_samples=2)
+
+
+def case_validate(name="validate_tiny", seed=31, D=6, C=4, S=3, sizes=(8, 8, 4)):
+    """``CVAE.validate`` (src/vae_models.py:327-337) over three ragged batches, once with 2-D conditions and once with
+    sampled (3-D) conditions ``[B,S,C]``; every latent draw is logged in call order."""
+    rng = np.random.default_rng(seed)
+    cfg = tiny_model_cfg("dict-gauss")
+    torch.manual_seed(seed)
+    model = CVAE(input_dim=D, conditioner=Cdim(C), **cfg)
+    _warm_bn(model, D, rng)
+    out = {"model_cfg": json.dumps(cfg), "D": D, "C": C, "S": S, "sizes": np.array(sizes)}
+    out.update(np_state(model.state_dict()))
+    n = sum(sizes)
+    for tag, three_d in (("2d", False), ("3d", True)):
+        batches = []
+        for i, b in enumerate(sizes):
+            x = torch.tensor(synth_profiles(b, D, rng))
+            c = torch.tensor(rng.normal(size=(b, S, C) if three_d else (b, C)).astype(np.float32))
+            batches.append((x, c))
+            out[f"{tag}_x{i}"], out[f"{tag}_c{i}"] = x.numpy(), c.numpy()
+        torch.manual_seed(seed + 5)
+        with DrawLog() as log:
+            val = model.validate(ListLoader(batches, n), num_mc_samples=S, beta=0.7, device="cpu")
+        assert len(log.randn) == len(sizes)
+        for i, e in enumerate(log.randn):
+            out[f"{tag}_eps{i}"] = e.numpy()
+        out[f"{tag}_val"] = np.array([val["elbo"], val["rll"], val["kl"]], dtype=np.float64)
+        assert not model.training
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, out["2d_val"], out["3d_val"])
+
+
+def case_fit(name="fit_tiny", seed=41, D=6, C=4, S=2, B=8, n_train=32, val_sizes=(8, 4), epochs=6):
+    """A short ``fit`` run of the reference (src/vae_models.py:126-238) on fixed batches: validation every 2 iterations
+    drives ReduceLROnPlateau(mode=max, threshold_mode=abs) and EarlyStopping (src/utils.py:156-180); the stop takes
+    effect at the end of the epoch it was raised in (:235).  Logged: every latent draw in call order, the loss terms of
+    every iteration, every validation result, the learning rate after every validation, the number of iterations run,
+    BatchNorm counters and the final state."""
+    import tempfile
+    rng = np.random.default_rng(seed)
+    cfg = tiny_model_cfg("dict-gauss")
+    torch.manual_seed(seed)
+    model = CVAE(input_dim=D, conditioner=Cdim(C), **cfg)
+    out = {"model_cfg": json.dumps(cfg), "D": D, "C": C, "S": S, "B": B}
+    out.update(np_state(model.state_dict()))
+    train = [(torch.tensor(synth_profiles(B, D, rng)), torch.tensor(rng.normal(size=(B, C)).astype(np.float32))) for _ in range(n_train // B)]
+    val = [(torch.tensor(synth_profiles(b, D, rng)), torch.tensor(rng.normal(size=(b, C)).astype(np.float32))) for b in val_sizes]
+    for i, (x, c) in enumerate(train):
+        out[f"train_x{i}"], out[f"train_c{i}"] = x.numpy(), c.numpy()
+    for i, (x, c) in enumerate(val):
+        out[f"val_x{i}"], out[f"val_c{i}"] = x.numpy(), c.numpy()
+    fit_kwargs = dict(lr=1e-3, weight_decay=1e-5, gradient_clipping=True, gradient_clipping_kwargs={"max_norm": 1.0},
+                      lr_scheduling=True, lr_scheduling_kwargs={"threshold": 15.0, "factor": 0.2, "patience": 1, "min_lr": 1e-5},
+                      beta=1.0, num_mc_samples=S, epochs=epochs, verbose_freq=1000, tensorboard=False, validation_freq=2,
+                      validation_mc_samples=3, device="cpu", earlystopping=True, earlystopping_kwargs={"patience": 2, "delta": 30.0},
+                      save_epoch_freq=None)
+    out["fit_kwargs"] = json.dumps(fit_kwargs)
+    train_log, val_log, lr_log = [], [], []
+    tc, vd = model.train_core, model.validate
+    holder = {}
+    def train_core(inputs, optim, **k):
+        holder["optim"] = optim
+        loss = tc(inputs, optim, **k)
+        train_log.append([loss[q].item() for q in ("loss", "elbo", "rll", "kl")])
+        return loss
+    def validate(*a, **k):
+        r = vd(*a, **k)
+        val_log.append([r["elbo"], r["rll"], r["kl"], len(train_log)])
+        return r
+    model.train_core, model.validate = train_core, validate
+    step_orig = torch.optim.lr_scheduler.ReduceLROnPlateau.step
+    def sched_step(self_, metrics, *a, **k):
+        r = step_orig(self_, metrics, *a, **k)
+        lr_log.append(self_.optimizer.param_groups[0]["lr"])
+        return r
+    torch.optim.lr_scheduler.ReduceLROnPlateau.step = sched_step
+
+    class W:
+        log_dir = tempfile.mkdtemp()
+
+    class Bar:                                      # the early-stopping call needs a progress bar object (:213)
+        def __init__(self, **k): pass
+        def update(self, n): pass
+        def reset(self): pass
+        def write(self, msg): print(msg)
+    torch.manual_seed(seed + 9)
+    try:
+        with DrawLog() as log:
+            model.fit(ListLoader(train, n_train), ListLoader(val, sum(val_sizes)), tqdm_func=Bar, writer=W(), **fit_kwargs)
+    finally:
+        torch.optim.lr_scheduler.ReduceLROnPlateau.step = step_orig
+    del model.train_core, model.validate
+    out["n_draws"] = len(log.randn)
+    for i, e in enumerate(log.randn):
+        out[f"eps_{i}"] = e.numpy()
+    out["train_losses"] = np.array(train_log, dtype=np.float64)
+    out["val_log"] = np.array(val_log, dtype=np.float64)
+    out["lr_log"] = np.array(lr_log, dtype=np.float64)
+    out["iterations"] = len(train_log)
+    out["training_after_fit"] = int(model.training)
+    out.update({"final::" + k: v.detach().numpy() for k, v in model.state_dict().items()})
+    # the control decisions must not sit on a knife edge: replaying them in fp32 on another device may not flip one
+    elbos = out["val_log"][:, 0]
+    margins = []
+    for thr in (fit_kwargs["lr_scheduling_kwargs"]["threshold"], fit_kwargs["earlystopping_kwargs"]["delta"]):
+        best = elbos[0]
+        for e in elbos[1:]:
+            margins.append(abs(e - (best + thr)))
+            if e > best + thr:
+                best = e
+    assert min(margins) > 0.05, f"a plateau / early-stopping decision sits {min(margins)} from its threshold: pick another seed"
+    assert len(set(lr_log)) > 1, "the run never changed the learning rate: lengthen it"
+    assert out["iterations"] < epochs * (n_train // B), "early stopping never fired: lengthen the run"
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, "iterations", out["iterations"], "val", out["val_log"].tolist(), "lr", lr_log, "margin", min(margins))
+
+
+def case_config0_sgd(name="config0_sgd_steps", seed=2112, B=64, S=4, steps=4, lr=0.1):
+    """config0 architecture, four ``train_core`` steps of the reference driven by plain SGD (``train_core`` takes whatever
+    optimiser it is given, src/vae_models.py:317-325) on gradients clipped to norm 1: every step moves the weights 0.1
+    along the gradient, so the loss terms of step t+1 test the whole backward pass of step t, and -- unlike Adam, whose
+    first updates are sign-like and turn round-off-sized gradients into +-lr moves -- the update is linear in the
+    gradient, so two fp32 implementations stay 1e-6 apart along the trajectory.  Stored per step: inputs, noise, loss
+    terms, the first 64 values of every clipped gradient; after the last step (sum, sum of squares) and the first 64
+    values of every state tensor."""
+    cfg = json.load(open(os.path.join(REF, "config_files", "config0.json")))
+    mcfg = cfg["model"]
+    D, C, L = 48, 4, mcfg["latent_dim"]
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    model = CVAE(input_dim=D, conditioner=Cdim(C), **mcfg)
+    model.train()
+    model.train_kwargs = {"num_mc_samples": S, "beta": cfg["train"]["beta"], "gradient_clipping": True,
+                          "gradient_clipping_kwargs": cfg["train"]["gradient_clipping_kwargs"]}
+    out = {"model_cfg": json.dumps(mcfg), "seed": seed, "D": D, "C": C, "B": B, "S": S, "lr": lr, "beta": cfg["train"]["beta"]}
+    optim = torch.optim.SGD(model.parameters(), lr=lr)
+    xs, cs, es, ls = [], [], [], []
+    names = [k for k, _ in model.named_parameters()]
+    for t in range(steps):
+        xb = torch.tensor(synth_profiles(B, D, rng))
+        ang = rng.uniform(0, 2 * np.pi, size=(B, 2))
+        cb = torch.tensor(np.concatenate([np.cos(ang), np.sin(ang)], 1).astype(np.float32))
+        torch.manual_seed(seed + 1000 + t)
+        eps = torch.randn((S, B, L))
+        torch.manual_seed(seed + 1000 + t)
+        loss = model.train_core((xb, cb), optim)
+        out[f"grad{t}"] = np.stack([np.resize(p.grad.detach().numpy().reshape(-1)[:64], 64) for _, p in model.named_parameters()])
+        xs.append(xb.numpy()); cs.append(cb.numpy()); es.append(eps.numpy())
+        ls.append([loss[k].item() for k in ("loss", "elbo", "rll", "kl")])
+        print("step", t, ls[-1], flush=True)
+    out["grad_keys"] = json.dumps(names)
+    out["steps_x"], out["steps_c"], out["steps_eps"] = np.stack(xs), np.stack(cs), np.stack(es)
+    out["steps_losses"] = np.array(ls, dtype=np.float64)
+    sd = model.state_dict()
+    keys = sorted(sd)
+    out["final_keys"] = json.dumps(keys)
+    out["final_sums"] = np.array([[float(sd[k].double().sum()), float((sd[k].double() ** 2).sum())] for k in keys])
+    out["final_head"] = np.stack([np.resize(sd[k].detach().double().numpy().reshape(-1)[:64], 64) for k in keys])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name)
+
+
 def case_pointwise(name="pointwise"):
     xs = torch.tensor([-30.0, -10.0, -1.0, 0.0, 1.0, 4.9, 5.0, 5.0001, 5.1, 10.0, 40.0])
     out = {"softplus_in": xs.numpy(), "softplus_out": ref_utils.to_sigma(xs).numpy()}
@@ -467,6 +646,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mh":           # only the Metropolis-within-Gibbs case
         case_imputation_mh()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "validate":     # only the validate case
+        case_validate()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fit":          # only the fit-loop case
+        case_fit()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sgd":          # only the config0 SGD-steps case
+        case_config0_sgd()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "nobn":         # only the case without BatchNorm
         case_forward_train("tiny_nobn_2d", "dict-gauss", seed=8, B=16, dropout=True, bn=False)
         sys.exit(0)
@@ -482,3 +670,6 @@ if __name__ == "__main__":
     case_imputation()
     case_imputation_mh()
     case_config0_shape()
+    case_validate()
+    case_fit()
+    case_config0_sgd()

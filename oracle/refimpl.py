@@ -394,12 +394,22 @@ def clip_and_adam(sd: Dict[str, Tensor], grads: Dict[str, Tensor], st: AdamState
     return total
 
 
-def train_step(sd: Dict[str, Tensor], spec: ModelSpec, st: AdamState, x: Tensor, c: Tensor, eps: Tensor,
+def clip_and_sgd(sd: Dict[str, Tensor], grads: Dict[str, Tensor], lr: float, max_norm: Optional[float]) -> float:
+    """``clip_grad_norm_(parameters, max_norm)`` then a plain ``torch.optim.SGD(lr)`` step (no momentum, no decay):
+    ``train_core`` steps whatever optimiser it is handed (src/vae_models.py:317-325).  Returns the pre-clip norm."""
+    total = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values()))
+    coef = min(max_norm / (total + 1e-6), 1.0) if max_norm is not None else 1.0
+    for k, g in grads.items():
+        sd[k] = (sd[k] - lr * (g * coef)).detach()
+    return total
+
+
+def train_step(sd: Dict[str, Tensor], spec: ModelSpec, st: Optional[AdamState], x: Tensor, c: Tensor, eps: Tensor,
                lr: float, weight_decay: float, beta: float = 1.0, max_norm: Optional[float] = 1.0,
-               keep_flags: Optional[List[Tensor]] = None):
+               keep_flags: Optional[List[Tensor]] = None, optimizer: str = "adam"):
     """One ``CVAE.train_core`` (src/vae_models.py:317-325): forward in train mode, loss, backward
-    (autograd on the restated forward), global-norm clip, Adam.  Mutates ``sd`` and ``st``.
-    Returns (loss dict of floats, gradient dict, pre-clip norm)."""
+    (autograd on the restated forward), global-norm clip, Adam (or plain SGD with ``optimizer="sgd"``).
+    Mutates ``sd`` and ``st``.  Returns (loss dict of floats, gradient dict, pre-clip norm)."""
     keys = parameter_keys(spec)
     leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
     work = dict(sd)
@@ -410,8 +420,101 @@ def train_step(sd: Dict[str, Tensor], spec: ModelSpec, st: AdamState, x: Tensor,
     gl = torch.autograd.grad(terms["loss"], [leaves[k] for k in keys])
     grads = {k: g.detach() for k, g in zip(keys, gl)}
     sd.update(upd)
-    norm = clip_and_adam(sd, grads, st, lr, weight_decay, max_norm)
+    if optimizer == "sgd":
+        norm = clip_and_sgd(sd, grads, lr, max_norm)
+    else:
+        norm = clip_and_adam(sd, grads, st, lr, weight_decay, max_norm)
     return {k: float(v.detach()) for k, v in terms.items()}, grads, norm
+
+
+def validate(sd: Dict[str, Tensor], spec: ModelSpec, batches: Sequence[Tuple[Tensor, Tensor]], eps_list: Sequence[Tensor],
+             n_dataset: int, beta: float = 1.0) -> Dict[str, float]:
+    """``CVAE.validate`` (src/vae_models.py:327-337): eval-mode forward per batch, loss terms weighted by the batch's
+    row count and divided by the dataset length.  ``eps_list[i]`` holds batch i's latent noise (any shape with
+    S*B*L elements)."""
+    tot = {"elbo": 0.0, "rll": 0.0, "kl": 0.0}
+    for (x, c), eps in zip(batches, eps_list):
+        S = eps.numel() // (x.shape[0] * spec.latent_dim)
+        lik, post, _ = cvae_forward(sd, spec, x, c, eps.reshape(S, x.shape[0], spec.latent_dim), False)
+        terms = elbo_terms(sd, spec, x, lik, post, beta)
+        for k in tot:
+            tot[k] += float(terms[k]) * x.shape[0]
+    return {k: v / n_dataset for k, v in tot.items()}
+
+
+class PlateauMax:
+    """``ReduceLROnPlateau(mode="max", threshold_mode="abs")`` as ``fit`` builds it (src/vae_models.py:181), restated
+    from torch's documented rule: a value is better when it exceeds best + threshold; after more than ``patience``
+    non-improving values in a row the rate is multiplied by ``factor`` (not below ``min_lr``, and only if the change
+    exceeds 1e-8) and the count restarts."""
+
+    def __init__(self, lr: float, threshold: float = 1e-4, factor: float = 0.1, patience: int = 10, min_lr: float = 0.0):
+        self.lr, self.threshold, self.factor, self.patience, self.min_lr = lr, threshold, factor, patience, min_lr
+        self.best, self.bad = -math.inf, 0
+
+    def step(self, value: float) -> float:
+        if value > self.best + self.threshold:
+            self.best, self.bad = value, 0
+        else:
+            self.bad += 1
+        if self.bad > self.patience:
+            new = max(self.lr * self.factor, self.min_lr)
+            if self.lr - new > 1e-8:
+                self.lr = new
+            self.bad = 0
+        return self.lr
+
+
+class EarlyStop:
+    """``EarlyStopping`` (src/utils.py:156-180): the first score only sets the best; later a score must beat
+    best + delta, else a counter runs up to ``patience``."""
+
+    def __init__(self, patience: int = 5, delta: float = 0.1):
+        self.patience, self.delta, self.best, self.count, self.stop = patience, delta, None, 0, False
+
+    def __call__(self, score: float):
+        if self.best is None:
+            self.best = score
+        elif self.stop:
+            return
+        elif score > self.best + self.delta:
+            self.best, self.count = score, 0
+        else:
+            self.count += 1
+            if self.count >= self.patience:
+                self.stop = True
+
+
+def fit_replay(sd: Dict[str, Tensor], spec: ModelSpec, train: Sequence[Tuple[Tensor, Tensor]], val: Sequence[Tuple[Tensor, Tensor]],
+               n_val: int, draws: Sequence[Tensor], lr: float, weight_decay: float, beta: float, max_norm: Optional[float],
+               epochs: int, validation_freq: int, plateau: Optional[dict], earlystopping: Optional[dict]):
+    """The cadence of ``VAE.fit`` (src/vae_models.py:188-235) over fixed batches with the latent noise taken from
+    ``draws`` in call order: ``train_core`` per batch; every ``validation_freq`` iterations ``validate`` (beta 1, :204),
+    whose ELBO drives the plateau rule and early stopping; a raised stop ends training after the current epoch (:235).
+    Returns (train loss terms per iteration, [elbo, rll, kl, iteration] per validation, learning rate after each
+    validation)."""
+    st = AdamState()
+    sched = PlateauMax(lr, **plateau) if plateau is not None else None
+    stopper = EarlyStop(**earlystopping) if earlystopping is not None else None
+    it = iter(draws)
+    L = spec.latent_dim
+    train_log, val_log, lr_log = [], [], []
+    for _ in range(epochs):
+        for x, c in train:
+            eps = next(it)
+            terms, _, _ = train_step(sd, spec, st, x, c, eps.reshape(-1, x.shape[0], L), lr=(sched.lr if sched else lr),
+                                     weight_decay=weight_decay, beta=beta, max_norm=max_norm)
+            train_log.append([terms[k] for k in ("loss", "elbo", "rll", "kl")])
+            if len(train_log) % validation_freq == 0 and val:
+                v = validate(sd, spec, val, [next(it) for _ in val], n_val, beta=1.0)
+                val_log.append([v["elbo"], v["rll"], v["kl"], len(train_log)])
+                if sched is not None:
+                    lr_log.append(sched.step(v["elbo"]))
+                if stopper is not None:
+                    stopper(v["elbo"])
+        if stopper is not None and stopper.stop:
+            break
+    return train_log, val_log, lr_log
 
 
 # ---------------------------------------------------------------------------------------------

@@ -422,6 +422,37 @@ def test_module_api_with_stock_optimizer(dev):
     assert torch.allclose(grads[1], 2 * grads[0], rtol=2e-3, atol=1e-6)
 
 
+def test_module_api_with_fused_optimizer(dev):
+    """The reference's idiom with the model's own optimiser: ``opt = model.get_optimizer()``, forward,
+    ``opt.zero_grad(set_to_none=True)``, ``loss.backward()``, clip, ``opt.step()``.  The autograd nodes accumulate
+    into the gradient arena, so ``FusedClipAdam.zero_grad`` has to clear it: the trajectory must equal the fused
+    ``train_core`` path and the reference over all recorded steps (gradients summed across steps would not)."""
+    g = load_golden("tiny_dict_2d")
+    ma, mb = build(g, dev), build(g, dev)
+    for m in (ma, mb):
+        m.train()
+        m.prior_params = {k: v.to(dev) for k, v in m.prior_params.items()}
+        m.train_kwargs = {"num_mc_samples": int(g["S"]), "beta": 0.7, "gradient_clipping": True, "gradient_clipping_kwargs": {"max_norm": 1.0}}
+    opt_a = ma.get_optimizer(lr=1e-3, weight_decay=1e-5)
+    opt_b = mb.get_optimizer(lr=1e-3, weight_decay=1e-5)
+    for t in range(g["steps_x"].shape[0]):
+        x, c, eps = T(g["steps_x"][t]).to(dev), T(g["steps_c"][t]).to(dev), T(g["steps_eps"][t]).to(dev)
+        with _FixedRandn(eps):
+            xd, zd = ma(x, c, num_mc_samples=eps.shape[0])
+        opt_a.zero_grad(set_to_none=True)
+        assert all(p.grad is not None for p in ma.parameters()) and float(ma._grad_arena.abs().max()) == 0.0
+        la = ma.loss(x, xd["params"], zd["params"], beta=0.7, prior_params=ma.prior_params)
+        la["loss"].backward()
+        opt_a.step(max_norm=1.0)
+        lb = mb._train_step(x, c, opt_b, eps=eps)
+        assert rel_err([la[k].item() for k in ("loss", "rll", "kl")], [lb[k].item() for k in ("loss", "rll", "kl")]) < 1e-4, t
+        assert rel_err([la[k].item() for k in ("loss", "elbo", "rll", "kl")], g["steps_losses"][t]) < 1e-4, t
+    sa, sb = ma.state_dict(), mb.state_dict()
+    for k, v in sa.items():
+        if v.is_floating_point():
+            assert (v - sb[k]).abs().max() <= 5e-4 * (sb[k].abs().max() + 1e-6), k
+
+
 def test_single_row_batch_in_train_mode_raises_like_batchnorm(dev):
     """A one-profile batch in train mode: torch's BatchNorm1d raises ValueError on the encoder's single row, and so
     does this path; eval mode accepts it."""

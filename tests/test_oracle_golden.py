@@ -1,6 +1,8 @@
 """CPU: the oracle restatement against every golden vector produced by the reference
 (tests/golden/*.npz, generator oracle/make_golden.py).  Tolerances are fp32 round-off of two
 differently ordered but mathematically identical CPU computations."""
+import json
+
 import numpy as np
 import pytest
 import torch
@@ -206,3 +208,88 @@ def test_metropolis_within_gibbs():
     assert np.allclose(cm.numpy(), g["cond_mean"], rtol=2e-4, atol=2e-5)
     assert np.allclose(cc.numpy(), g["cond_cov"], rtol=2e-4, atol=2e-6)
     assert np.allclose(cs.numpy(), g["cond_samples"], rtol=2e-4, atol=2e-5)
+
+
+class _Cdim:
+    def __init__(self, c):
+        self.cond_dim = c
+
+
+def _seeded_state(g):
+    """Seed-exact initial weights of the reference's constructor (pinned by ``test_seeded_construction_matches_reference``)."""
+    import contextlib, io
+    from behavio_temporal_vae_amd.vae_models import CVAE
+    cfg = json.loads(str(g["model_cfg"]))
+    torch.manual_seed(int(g["seed"]))
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = CVAE(input_dim=int(g["D"]), conditioner=_Cdim(int(g["C"])), **cfg)
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def test_config0_sgd_steps():
+    """config0 architecture, four gradient-driven (clipped SGD) steps of the reference: loss terms of every step,
+    clipped-gradient slices, and the final state's checksums."""
+    g = load_golden("config0_sgd_steps")
+    spec, _ = golden_spec(g)
+    sd = _seeded_state(g)
+    names = json.loads(str(g["grad_keys"]))
+    for t in range(g["steps_x"].shape[0]):
+        terms, grads, norm = R.train_step(sd, spec, None, T(g["steps_x"][t]), T(g["steps_c"][t]), T(g["steps_eps"][t]),
+                                          lr=float(g["lr"]), weight_decay=0.0, beta=float(g["beta"]), max_norm=1.0, optimizer="sgd")
+        got = [terms[k] for k in ("loss", "elbo", "rll", "kl")]
+        assert rel_err(got, g["steps_losses"][t]) < (1e-5 if t < 2 else 3e-5), (t, got, g["steps_losses"][t])
+        if t > 0:
+            continue
+        # Clipped-gradient slices at the shared initial state.  The pre-clip gradient norm is ~2e4 here (sums over 256
+        # rows that cancel heavily): the reference's own fp32 gradients sit 2e-3 (of a slice's largest entry) from the
+        # fp64 ones, so 5e-3 is the resolution of this check; at later steps the states have drifted within the 1e-4 band
+        # and single gradient entries differ by percents, so there the loss terms carry the comparison.
+        coef = min(1.0 / (norm + 1e-6), 1.0)
+        ref = g[f"grad{t}"]
+        for i, k in enumerate(names):
+            n = min(64, grads[k].numel())
+            mine = (grads[k].reshape(-1)[:n] * coef).numpy()
+            assert np.abs(mine - ref[i][:n]).max() <= 5e-3 * np.abs(ref[i][:n]).max() + 1e-7, (t, k)
+    keys = json.loads(str(g["final_keys"]))
+    for i, k in enumerate(keys):
+        v = sd[k].double()
+        assert abs(float(v.sum()) - g["final_sums"][i][0]) <= 2e-3 * float(v.abs().sum()) + 1e-6, k
+        assert abs(float((v ** 2).sum()) - g["final_sums"][i][1]) <= 5e-3 * g["final_sums"][i][1] + 1e-9, k
+
+
+@pytest.mark.parametrize("tag", ["2d", "3d"])
+def test_validate(tag):
+    g = load_golden("validate_tiny")
+    spec, _ = golden_spec(g)
+    sd = golden_state(g)
+    n = int(g["sizes"].sum())
+    batches = [(T(g[f"{tag}_x{i}"]), T(g[f"{tag}_c{i}"])) for i in range(len(g["sizes"]))]
+    eps = [T(g[f"{tag}_eps{i}"]) for i in range(len(g["sizes"]))]
+    val = R.validate(sd, spec, batches, eps, n, beta=0.7)
+    assert rel_err([val["elbo"], val["rll"], val["kl"]], g[f"{tag}_val"]) < 1e-5
+
+
+def test_fit_cadence():
+    """The reference's ``fit`` run: the oracle replays it from the logged noise and must reproduce every train and
+    validation number, the learning-rate changes, the early-stopping iteration and the final state."""
+    g = load_golden("fit_tiny")
+    spec, _ = golden_spec(g)
+    sd = golden_state(g)
+    kw = json.loads(str(g["fit_kwargs"]))
+    train = [(T(g[f"train_x{i}"]), T(g[f"train_c{i}"])) for i in range(4)]
+    val = [(T(g[f"val_x{i}"]), T(g[f"val_c{i}"])) for i in range(2)]
+    draws = [T(g[f"eps_{i}"]) for i in range(int(g["n_draws"]))]
+    tl, vl, ll = R.fit_replay(sd, spec, train, val, sum(v[0].shape[0] for v in val), draws, lr=kw["lr"], weight_decay=kw["weight_decay"],
+                              beta=kw["beta"], max_norm=kw["gradient_clipping_kwargs"]["max_norm"], epochs=kw["epochs"],
+                              validation_freq=kw["validation_freq"], plateau=kw["lr_scheduling_kwargs"], earlystopping=kw["earlystopping_kwargs"])
+    assert len(tl) == int(g["iterations"])
+    assert rel_err(np.array(tl), g["train_losses"]) < 1e-4
+    assert np.array_equal(np.array(vl)[:, 3], g["val_log"][:, 3])
+    assert rel_err(np.array(vl)[:, :3], g["val_log"][:, :3]) < 1e-4
+    assert np.allclose(ll, g["lr_log"], rtol=1e-12)
+    for k, v in sd.items():
+        ref = g["final::" + k]
+        if v.is_floating_point():
+            assert np.abs(v.numpy() - ref).max() <= 5e-4 * (np.abs(ref).max() + 1e-6), k
+        else:
+            assert int(v) == int(ref), k
