@@ -140,6 +140,53 @@ def test_iw_scoring_properties_large(dev):
     assert torch.isfinite(l1).all() and (a >= l1 - math.log(K) - 1e-3).all()
 
 
+@pytest.mark.timeout(600)
+def test_gipuzkoa_k1000_scoring_vs_oracle(dev):
+    """The scoring benchmark's own shape -- config0_gipuzkoa model (D=L=24, C=4, H=1000, V=100, eval mode with
+    non-trivial BatchNorm running statistics), K=1000 latent draws -- on 64 profiles against the fp64 CPU oracle with
+    the same injected noise: per-draw log-likelihoods, the importance-weighted log-likelihood and KL at 1e-4, in the
+    chunking the benchmark uses (25 draws per decoder pass)."""
+    import contextlib, io
+    from oracle import refimpl as R
+    from behavio_temporal_vae_amd import testing_lib
+    from behavio_temporal_vae_amd.vae_models import CVAE
+    cfg = {"latent_dim": 24, "distribution_dict": {
+        "posterior": {"dist_type": "normal", "learn_sigma": True, "sigma_lim": 0.05, "average_max_std": 1.0, "mu_upper_lim": 5.0,
+                      "mu_lower_lim": -5.0, "num_neurons": 1000, "num_hidden_layers": 2, "dropout": True, "dropout_rate": 0.2,
+                      "batch_normalization": True, "resnet": False},
+        "likelihood": {"dist_type": "dict-gauss", "vocab_size": 100, "learn_sigma": True, "sigma_lim": 1e-6, "marginal_std_lim": 0.05,
+                       "average_max_std": 1.0, "mu_upper_lim": 5.0, "mu_lower_lim": -3, "num_neurons": 1000, "num_hidden_layers": 2,
+                       "dropout": True, "dropout_rate": 0.2, "batch_normalization": True, "resnet": False}}}
+
+    class C4:
+        cond_dim = 4
+    N, K, D, L = 64, 1000, 24, 24
+    torch.manual_seed(2112)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = CVAE(input_dim=D, conditioner=C4(), **cfg)
+    gen = torch.Generator().manual_seed(8)
+    sd = m.state_dict()
+    for k, v in sd.items():                       # running statistics as after some training, not (0, 1)
+        if k.endswith("running_mean"):
+            v.copy_(0.3 * torch.randn(v.shape, generator=gen))
+        elif k.endswith("running_var"):
+            v.copy_(0.5 + torch.rand(v.shape, generator=gen))
+    m.load_state_dict(sd)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(N, D, generator=gen).add_(1.0).clamp_(-3, 5)
+    ang = torch.rand(N, 2, generator=gen) * (2 * math.pi)
+    c = torch.cat([torch.cos(ang), torch.sin(ang)], 1)
+    eps = torch.randn(K, N, L, generator=gen)
+    spec = R.model_spec(D, 4, cfg)
+    with torch.no_grad():
+        ll64, rl64, kl64 = R.iw_loglikelihood(R.cast_state(sd, torch.float64), spec, x.double(), c.double(), eps.double())
+    m = m.to(dev).eval()
+    ll, rlls, kl = testing_lib.iw_loglikelihood_device(m, x.to(dev), c.to(dev), K, mc_sample_batch_size=25, eps=eps.to(dev), return_rlls=True)
+    assert rel_err(rlls.cpu().numpy(), rl64.numpy()) < 1e-4
+    assert rel_err(ll.cpu().numpy(), ll64.numpy()) < 1e-4
+    assert rel_err(kl.cpu().numpy(), kl64.numpy()) < 1e-4
+
+
 def test_pseudo_gibbs_vs_reference(dev):
     from behavio_temporal_vae_amd import imputation_lib
     g = load_golden("imputation_tiny")
