@@ -5,6 +5,11 @@ conditional Gaussian of the missing coordinates given the observed ones and one 
 profile, ``btvae_cond_mvn_sample``) -> row-major masked write-back into ``x``.  Index and mask handling follows
 the reference exactly: observed indices are read from row 0 of the mask only, ring-buffer slot is
 ``itx % num_samples``, the write-back consumes ``samples.flatten()`` in row-major mask order.
+
+Two deliberate differences from the reference, both on code the reference's own scripts never reach with its shipped
+configs: ``pseudo_gibbs`` stores every row's posterior parameters in ``z_rec["params"]`` (the reference writes row 0's
+to all rows, src/imputation_lib.py:89), and the Normal-decoder conditional uses the unobserved coordinates' sigmas
+(the reference indexes the observed ones, :37-38).  A profile with nothing missing raises ``ValueError``.
 """
 from __future__ import annotations
 
@@ -36,46 +41,67 @@ def _index_sets(D, observed_indices):
     return obs, un
 
 
-def _cond_rows(model, mu, sigma, x_full, eps, obs, un):
-    """Kernel call on flattened rows: returns (samples, mean, cov) with shapes [rows,U], [rows,U], [rows,U,U]."""
-    D, U = model.output_dim, len(un)
+class CondSplit:
+    """The observed / unobserved partition of the D coordinates as the kernel wants it (bit mask of the observed ones,
+    rank of every coordinate among the unobserved ones as a device array).  It is the same for every sweep of a chain,
+    so the chains build it once (one host-to-device copy) instead of once per sweep."""
+
+    def __init__(self, D, observed_indices, device):
+        self.obs, self.un = _index_sets(D, observed_indices)
+        self.D, self.U = D, len(self.un)
+        if self.U == 0:
+            raise ValueError("nothing to impute: every coordinate is observed")
+        self.mask = 0
+        for i in self.obs:
+            self.mask |= 1 << i
+        un_pos = torch.zeros(D, dtype=torch.int32)
+        for r_, i in enumerate(self.un):
+            un_pos[i] = r_
+        self.un_pos = un_pos.to(device)
+        self.obs_index = torch.tensor(self.obs, dtype=torch.long, device=device)
+
+
+def _cond_rows(model, mu, sigma, x_full, eps, split):
+    """Kernel call on flattened rows: returns (samples, mean, cov) with shapes [rows,U], [rows,U], [rows,U,U].
+    ``x_full[rows, D]`` is read at the observed coordinates only."""
+    D, U = model.output_dim, split.U
     rows = mu.shape[0]
     dev = mu.device
     nv.ensure_device(dev)
     tab = model.tables()
     Sp = E.dict_covariance_packed(tab, (sigma * sigma).contiguous())
-    mask = 0
-    for i in obs:
-        mask |= 1 << i
-    un_pos = torch.zeros(D, dtype=torch.int32)
-    for r_, i in enumerate(un):
-        un_pos[i] = r_
-    un_pos = un_pos.to(dev)
     samp, mean = torch.empty(rows, U, device=dev), torch.empty(rows, U, device=dev)
     cov = torch.empty(rows, U, U, device=dev)
-    nv.call("btvae_cond_mvn_sample", nv.ptr(Sp), nv.ptr(mu), nv.ptr(x_full), nv.ptr(eps), mask, nv.ptr(un_pos), nv.ptr(samp), nv.ptr(mean),
-            nv.ptr(cov), rows, D, U)
+    nv.call("btvae_cond_mvn_sample", nv.ptr(Sp), nv.ptr(mu), nv.ptr(x_full), nv.ptr(eps), split.mask, nv.ptr(split.un_pos), nv.ptr(samp),
+            nv.ptr(mean), nv.ptr(cov), rows, D, U)
     return samp, mean, cov
 
 
-def _conditional(model, param_dict, x_observed, observed_indices, eps=None):
+def _conditional(model, param_dict, x_observed, observed_indices, eps=None, split=None, x_full=None):
+    """``split`` / ``x_full`` (the whole ``[rows, D]`` profile tensor, read at the observed coordinates only) let a chain
+    skip rebuilding the partition and the scattered copy of ``x_observed`` on every sweep."""
     D = model.output_dim
-    obs, un = _index_sets(D, observed_indices)
     mu = param_dict["mu"]
+    if split is None:
+        split = CondSplit(D, observed_indices, mu.device)
+    obs, un = split.obs, split.un
     lead = mu.shape[:-1]
     mu_r = nv.f32(mu.reshape(-1, D))
     if isinstance(model, submodels.DictionaryGaussian):
         sg_r = nv.f32(param_dict["sigma"].reshape(-1, model.vocab_size))
-        xo = x_observed.expand(*lead, len(obs)).reshape(-1, len(obs))
-        x_full = torch.zeros(mu_r.shape[0], D, device=mu.device)
-        x_full[:, obs] = xo.float()
+        if x_full is None or x_full.shape != mu_r.shape or not x_full.is_contiguous() or x_full.dtype != torch.float32:
+            xo = x_observed.expand(*lead, len(obs)).reshape(-1, len(obs))
+            x_full = torch.zeros(mu_r.shape[0], D, device=mu.device)
+            x_full[:, split.obs_index] = xo.float()
         if eps is None:
             eps = torch.zeros(mu_r.shape[0], len(un), device=mu.device)
-        samp, mean, cov = _cond_rows(model, mu_r, sg_r, x_full, nv.f32(eps.reshape(-1, len(un))), obs, un)
+        samp, mean, cov = _cond_rows(model, mu_r, sg_r, x_full, nv.f32(eps.reshape(-1, len(un))), split)
         U = len(un)
         return samp.view(*lead, U), mean.view(*lead, U), cov.view(*lead, U, U)
     if isinstance(model, submodels.GaussianNN):
-        # independent coordinates: conditioning leaves the unobserved marginals unchanged
+        # Independent coordinates: conditioning leaves the unobserved marginals as they are.  The reference builds this
+        # covariance from the sigmas of the OBSERVED coordinates (src/imputation_lib.py:37-38), which has the wrong
+        # coordinates and, when the two sets differ in size, the wrong shape; that is not reproduced.
         mean = param_dict["mu"][..., un]
         sg = param_dict["sigma"][..., un]
         cov = torch.diag_embed(sg ** 2)
@@ -95,13 +121,13 @@ def get_conditional_params(model, param_dict, x_observed, observed_indices):
 
 @timing_decorator
 @torch.no_grad()
-def sample_conditional(model, param_dict, x_observed, observed_indices, num_samples=1):
+def sample_conditional(model, param_dict, x_observed, observed_indices, num_samples=1, split=None, x_full=None):
     """One draw mean + chol(cov) eps plus the conditional parameters (reference: src/imputation_lib.py:44-57)."""
     D = model.output_dim
-    _, un = _index_sets(D, observed_indices)
+    U = split.U if split is not None else len(_index_sets(D, observed_indices)[1])
     lead = param_dict["mu"].shape[:-1]
-    eps = torch.randn((*lead, len(un)), device=param_dict["mu"].device)
-    return _conditional(model, param_dict, x_observed, observed_indices, eps=eps)
+    eps = torch.randn((*lead, U), device=param_dict["mu"].device)
+    return _conditional(model, param_dict, x_observed, observed_indices, eps=eps, split=split, x_full=x_full)
 
 
 def _conditions_tensor(conditioner, condition_set, device):
@@ -129,9 +155,9 @@ def pseudo_gibbs(model, x, missing_mask, conditioner, condition_set, num_samples
     buffers (cond_x_samples, cond_x_mean, cond_x_cov, x_rec, z_rec) of the last ``num_samples`` sweeps."""
     observed_indices = torch.where((~missing_mask)[0])[0]     # row 0 only, as the reference does
     B, D, L = x.shape[0], model.input_dim, model.latent_dim
-    obs, un = _index_sets(D, observed_indices)
-    U = len(un)
     dev = x.device
+    split = CondSplit(D, observed_indices, dev)
+    U = split.U
     dec = model.decoder
     # the reference probes shapes with one forward of row 0 and one conditional draw; consume the same RNG draws
     torch.randn((1, 1, L), device=dev); torch.randn((1, U), device=dev)
@@ -151,7 +177,8 @@ def pseudo_gibbs(model, x, missing_mask, conditioner, condition_set, num_samples
         x_rec_, z_rec_ = model.forward(x, conditions)
         slot = itx % num_samples
         params0 = {k: v[0] for k, v in x_rec_["params"].items()}
-        s, m, c = sample_conditional(dec, params0, x[:, observed_indices], observed_indices)
+        # x itself serves as the kernel's profile tensor: it is read at the observed coordinates only
+        s, m, c = sample_conditional(dec, params0, None, observed_indices, split=split, x_full=x)
         cond_x_samples[slot], cond_x_mean[slot], cond_x_cov[slot] = s, m, c
         for k, v in x_rec_["params"].items():
             x_rec["params"][k][slot] = v[0]
@@ -171,9 +198,9 @@ def metropolis_within_gibbs(model, x, missing_mask, conditioner, condition_set, 
     z' ~ q(z|x,c), accept with min(1, w(z')/w(z)), w = p(x|z)p(z)/q(z|x); then redraw the missing coordinates."""
     observed_indices = torch.where((~missing_mask)[0])[0]
     B, D, L = x.shape[0], model.input_dim, model.latent_dim
-    obs, un = _index_sets(D, observed_indices)
-    U = len(un)
     dev = x.device
+    split = CondSplit(D, observed_indices, dev)
+    U = split.U
     enc, dec = model.encoder, model.decoder
     conditions = _conditions_tensor(conditioner, condition_set, device)
     z = enc.sample(enc(torch.cat((x, conditions), dim=-1)))[0]
@@ -206,7 +233,7 @@ def metropolis_within_gibbs(model, x, missing_mask, conditioner, condition_set, 
             x_params[k][acc] = v[acc]
         accepted += acc.shape[0]
         slot = itx % num_samples
-        s, m, c = sample_conditional(dec, x_params, x[:, observed_indices], observed_indices)
+        s, m, c = sample_conditional(dec, x_params, None, observed_indices, split=split, x_full=x)
         cond_x_samples[slot], cond_x_mean[slot], cond_x_cov[slot] = s, m, c
         nv.call("btvae_masked_scatter", nv.ptr(x), nv.ptr(idx), nv.ptr(cond_x_samples[slot]), idx.numel())
         if (itx + 1) % verbose_freq == 0:

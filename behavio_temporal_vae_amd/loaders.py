@@ -38,7 +38,9 @@ class DeviceBatchLoader:
 
     def __len__(self):
         n, gb = len(self.dataset), self.batch_sampler.batch_size * self.world
-        return n // gb if self.drop_last else (n + gb - 1) // gb
+        if self.drop_last:
+            return n // gb
+        return n // gb + (1 if (n % gb) // self.world > 0 else 0)
 
     def _order(self):
         n = len(self.dataset)
@@ -60,6 +62,13 @@ class DeviceBatchLoader:
             glob = order[g0:g0 + gb]
             if glob.numel() < gb and self.drop_last:
                 break
+            if self.world > 1 and glob.numel() % self.world:
+                # a ragged last global batch: every rank must get the same number of rows (the gradient average and
+                # cross-rank BatchNorm statistics weigh ranks equally, and no rank may be left without rows), so the
+                # last (fewer than world) indices of the epoch are dropped
+                glob = glob[:glob.numel() - glob.numel() % self.world]
+                if glob.numel() == 0:
+                    break
             b, e = shard_range(glob.numel(), self.rank, self.world)
             idx = glob[b:e]
             idx_d = idx.to(self.device)

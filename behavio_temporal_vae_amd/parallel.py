@@ -4,7 +4,17 @@ The path shards by data.  Training: every rank holds the full 41.6 MB of weights
 the flat gradient arena is all-reduced in four spans as their gradients become final (each network's heads, then
 its trunk; everything but the encoder trunk overlaps later backward work), then averaged, before the fused clip + Adam step — so clipping sees the same averaged gradient a single-device step on
 the global batch would.  Scoring / imputation: profiles are split into contiguous per-rank ranges and the only
-collective is one reduce of (sum of log-likelihoods, count).
+collective is one reduce of (sum of log-likelihoods, count); when there are too few profiles per GPU to fill the
+machine the Monte-Carlo draws can be split instead, each rank keeping a running (max, sum of exp) per profile that two
+all-reduces combine (``combine_lse``).
+
+Ordering of the asynchronous gradient all-reduce on RCCL: ``dist.all_reduce(..., async_op=True)`` makes RCCL's own
+stream wait on an event recorded on torch's current stream at the moment of the call, and the library's kernels are
+launched on that same current stream, so the reduction of a span starts after every kernel that wrote it; kernels
+enqueued later only write other spans (a network's heads and trunk occupy disjoint ranges of the arena, and gradients
+are overwritten once per step, never touched again before ``finish``).  ``finish()`` (``Work.wait``) makes the current
+stream wait for the reductions before the scale kernel and the optimiser read the arena, and the next step's backward
+is enqueued behind those on the same stream.
 """
 from __future__ import annotations
 
@@ -29,6 +39,31 @@ def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     else:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def all_reduce_max_(t: torch.Tensor, group=None) -> torch.Tensor:
+    if t.is_cuda and _staged(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
+
+
+def combine_lse(m_run: torch.Tensor, s_run: torch.Tensor, group=None):
+    """Merge per-rank running log-sum-exp states over disjoint sets of Monte-Carlo draws: every rank holds, per
+    profile, m = max of its log-weights and s = sum of exp(log-weight - m).  One all-reduce(max) gives the global
+    maximum, one all-reduce(sum) of the rescaled sums the global sum; log-sum-exp over all draws is m + log(s)
+    (the combination the importance-weighted estimate of src/testing_lib.py:14 needs when K is split).  A rank with no
+    draws passes m = -inf, s = 0.  In place; returns (m, s)."""
+    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        return m_run, s_run
+    local_m = m_run.clone()
+    all_reduce_max_(m_run, group)
+    s_run.mul_(torch.where(torch.isfinite(local_m), torch.exp(local_m - m_run), torch.zeros_like(s_run)))
+    all_reduce_sum_(s_run, group)
+    return m_run, s_run
 
 
 def all_gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:

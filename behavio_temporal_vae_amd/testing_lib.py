@@ -47,23 +47,38 @@ def _chunks(K, step):
 
 
 @torch.no_grad()
-def iw_loglikelihood_device(model, x, c, num_mc_samples, mc_sample_batch_size=100, eps=None, return_rlls=False):
+def iw_loglikelihood_device(model, x, c, num_mc_samples, mc_sample_batch_size=100, eps=None, return_rlls=False, k_shard=None):
     """Importance-weighted log-likelihood of device-resident profiles ``x[N,D]`` with conditions ``c[N,C]``:
     ll[n] = -log K + logsumexp_k(-log q(z_k) + log p(x|z_k) + log p(z_k)) (reference: src/testing_lib.py:10-14).
-    Everything stays on the device; ``eps[K,N,L]`` may be injected (tests), else it is drawn per chunk."""
+    Everything stays on the device; ``eps[K,N,L]`` may be injected (tests), else it is drawn per chunk.
+
+    ``k_shard=(rank, world[, group])`` splits the K draws over the ranks of a process group instead of the profiles
+    (every rank passes the same ``x``): rank r runs draws ``shard_range(K, r, world)`` and the per-profile running
+    (max, sum) states are merged by ``parallel.combine_lse`` -- two all-reduces of N floats -- so every rank returns the
+    full-K ``ll``.  ``rlls`` then holds this rank's draws only (rows ``k0:k1``, the rest zero)."""
     model._check_arena()
     N, L, K = x.shape[0], model.latent_dim, num_mc_samples
     x, c = nv.f32(x), nv.f32(c)
     post = _encode(model, x, c)
-    m_run, s_run = torch.empty(N, device=x.device), torch.empty(N, device=x.device)
-    rlls = torch.empty(K, N, device=x.device) if return_rlls else None
-    for i0, i1 in _chunks(K, mc_sample_batch_size):
+    m_run = torch.full((N,), -math.inf, device=x.device)
+    s_run = torch.zeros(N, device=x.device)
+    rlls = (torch.zeros(K, N, device=x.device) if k_shard is not None else torch.empty(K, N, device=x.device)) if return_rlls else None
+    k0, k1, group = 0, K, None
+    if k_shard is not None:
+        from .loaders import shard_range
+        k0, k1 = shard_range(K, int(k_shard[0]), int(k_shard[1]))
+        group = k_shard[2] if len(k_shard) > 2 else None
+    for j0, j1 in _chunks(k1 - k0, mc_sample_batch_size):
+        i0, i1 = k0 + j0, k0 + j1
         e = eps[i0:i1].contiguous() if eps is not None else torch.randn((i1 - i0, N, L), device=x.device)
         _, _, logp = _decode_chunk(model, post, c, e, x, N)
         nv.call("btvae_iw_lse_update", nv.ptr(logp), nv.ptr(e.reshape(-1, L)), nv.ptr(post["mu"]), nv.ptr(post["sigma"]),
-                nv.ptr(m_run), nv.ptr(s_run), i1 - i0, N, L, int(i0 == 0))
+                nv.ptr(m_run), nv.ptr(s_run), i1 - i0, N, L, int(j0 == 0))
         if rlls is not None:
             rlls[i0:i1] = logp
+    if k_shard is not None:
+        from .parallel import combine_lse
+        combine_lse(m_run, s_run, group)
     ll = torch.empty(N, device=x.device)
     nv.call("btvae_iw_lse_finalize", nv.ptr(m_run), nv.ptr(s_run), nv.ptr(ll), N, K)
     # per-profile KL to the standard-normal prior (reference: src/testing_lib.py:12)

@@ -2,9 +2,13 @@
 ``main(config)`` / ``train_model`` signatures, running the HIP path.
 
 The config schema is the reference's (``data`` / ``model`` / ``train`` sections, ``save_dir``, ``save_tag``).
-When the dataset named by ``config["data"]`` is not on disk, seeded synthetic profiles of the same shape are
-used (``--synthetic-train/--synthetic-val`` sizes).  Conditions are encoded once and batches are assembled on
-the device, instead of a per-item transform in DataLoader workers.
+Real data comes in as arrays: ``--train_npz`` / ``--val_npz`` name ``.npz`` files holding ``X [N,D]`` (the normalised
+profiles the reference's ``prepare_data`` would hand to the model, scripts/training.py:29) and one ``cond_<tag> [N,.]``
+array per entry of ``data.condition_tag_list`` -- the same layout ``scripts/collect_*_results.py --test_npz`` reads
+(``X_train`` / ``X_val`` / ``X_test`` are accepted as names for ``X``).  The reference's CSV preprocessing itself
+(src/preprocess_lib.py) is not part of this package.  Without ``--train_npz`` the run falls back to seeded synthetic
+profiles of the config's shape (``--synthetic-train/--synthetic-val`` sizes).  Conditions are encoded once and batches
+are assembled on the device, instead of a per-item transform in DataLoader workers.
 """
 import argparse
 import datetime
@@ -12,6 +16,7 @@ import json
 import os
 import sys
 
+import numpy as np
 import torch
 
 sys.path.append(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -45,8 +50,53 @@ def train_model(model, trainset, valset, train_kwargs, writer=None):
     return model
 
 
-def main(config, n_train=65536, n_val=8192):
-    trainset, valset, conditioner = prepare_synthetic_data(config["data"], n_train, n_val)
+CONDITION_TYPES = {"months": ("circ", list(range(1, 13))), "weekdays": ("circ", list(range(7))), "day_befores": ("identity", None),
+                   "users": ("dir", None)}
+
+
+def _npz_split(path):
+    """(X, {tag: array}) from an ``.npz`` split file."""
+    z = np.load(path, allow_pickle=False)
+    xkey = next((k for k in ("X", "X_train", "X_val", "X_test") if k in z.files), None)
+    if xkey is None:
+        raise ValueError(f"{path}: no profile array (X, X_train, X_val or X_test)")
+    conds = {k[len("cond_"):]: z[k] for k in z.files if k.startswith("cond_")}
+    return np.ascontiguousarray(z[xkey], dtype=np.float32), conds
+
+
+def prepare_npz_data(data_cfg, train_npz, val_npz=None):
+    """(trainset, valset, conditioner) from array files.  Condition types follow the reference's tag conventions
+    (src/conditioning_lib.py:141-173: months / weekdays circular, day_befores identity, users Dirichlet concentration
+    vectors); the conditioner is fitted on the training split."""
+    from behavio_temporal_vae_amd.conditioning_lib import Conditioner
+    from behavio_temporal_vae_amd.datasets import ConditionedDataset
+    tags = list(data_cfg.get("condition_tag_list", ["months", "weekdays"]))
+    xtr, ctr = _npz_split(train_npz)
+    missing = [t for t in tags if t not in ctr]
+    if missing:
+        raise ValueError(f"{train_npz}: missing condition arrays {['cond_' + t for t in missing]}")
+    ctr = {t: (ctr[t] if ctr[t].ndim == 2 else ctr[t][:, None]) for t in tags}
+    unknown = [t for t in tags if t not in CONDITION_TYPES]
+    if unknown:
+        raise NotImplementedError(f"condition tags {unknown} have no type convention here")
+    types = [CONDITION_TYPES[t][0] for t in tags]
+    supports = [CONDITION_TYPES[t][1] if CONDITION_TYPES[t][1] is not None else [float(ctr[t].min()), float(ctr[t].max())] for t in tags]
+    cond = Conditioner(tags=tags, supports=supports, types=types, condition_set=ctr)
+    trainset = ConditionedDataset(xtr, ctr, cond)
+    if val_npz is None:
+        n_val = max(1, min(xtr.shape[0] // 10, 8192))
+        xva, cva = xtr[-n_val:], {t: v[-n_val:] for t, v in ctr.items()}
+    else:
+        xva, cva = _npz_split(val_npz)
+        cva = {t: (cva[t] if cva[t].ndim == 2 else cva[t][:, None]) for t in tags}
+    return trainset, ConditionedDataset(xva, cva, cond), cond
+
+
+def main(config, n_train=65536, n_val=8192, train_npz=None, val_npz=None):
+    if train_npz is not None:
+        trainset, valset, conditioner = prepare_npz_data(config["data"], train_npz, val_npz)
+    else:
+        trainset, valset, conditioner = prepare_synthetic_data(config["data"], n_train, n_val)
     valset.num_samples = config["train"]["validation_mc_samples"]
     model = CVAE(input_dim=trainset.inputs.shape[-1], conditioner=conditioner, **config["model"])
     print("Number of encoder parameters:", model.encoder._num_parameters())
@@ -68,6 +118,8 @@ def main(config, n_train=65536, n_val=8192):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser(description="Train a conditional VAE with the configuration from a JSON file.")
     ap.add_argument("--config_path", type=str, default="./config_files/config0.json", help="Path to the JSON configuration file.")
+    ap.add_argument("--train_npz", type=str, default=None, help="training split as arrays (X, cond_<tag>); default: synthetic profiles")
+    ap.add_argument("--val_npz", type=str, default=None, help="validation split as arrays; default: the last tenth of the training split")
     ap.add_argument("--synthetic-train", type=int, default=65536)
     ap.add_argument("--synthetic-val", type=int, default=8192)
     ap.add_argument("--epochs", type=int, default=None, help="override train.epochs")
@@ -75,4 +127,4 @@ if __name__ == "__main__":
     cfg = load_config(args.config_path)
     if args.epochs is not None:
         cfg["train"]["epochs"] = args.epochs
-    main(cfg, args.synthetic_train, args.synthetic_val)
+    main(cfg, args.synthetic_train, args.synthetic_val, train_npz=args.train_npz, val_npz=args.val_npz)

@@ -68,6 +68,20 @@ def _worker(rank, world, port, q):
             out[mode] = (np.array(losses), sd)
             from behavio_temporal_vae_amd import engine as E
             E.BN_SYNC = None
+        # scoring with the Monte-Carlo draws split over the ranks (same profiles on both), ragged chunks
+        from behavio_temporal_vae_amd import testing_lib
+        gs = load_golden("scoring_tiny")
+        cfg = json.loads(str(gs["model_cfg"]))
+        from behavio_temporal_vae_amd.vae_models import CVAE
+        ms = CVAE(input_dim=int(gs["D"]), conditioner=Cdim(4), **cfg)
+        ms.load_state_dict(golden_state(gs))
+        ms = ms.to(dev).eval()
+        xs, cs, es = T(gs["x"]), T(gs["c"]), T(gs["eps"])
+        K = int(gs["K"])
+        ll_full, _, _ = testing_lib.iw_loglikelihood_device(ms, xs, cs, K, mc_sample_batch_size=3, eps=es)
+        ll_shard, rl_shard, _ = testing_lib.iw_loglikelihood_device(ms, xs, cs, K, mc_sample_batch_size=2, eps=es, return_rlls=True,
+                                                                    k_shard=(rank, world))
+        out["score"] = (ll_full.cpu().numpy(), ll_shard.cpu().numpy(), rl_shard.cpu().numpy())
         q.put((rank, out, None))
         dist.destroy_process_group()
     except Exception as exc:     # surface the failure in the parent instead of a silent non-zero exit
@@ -101,3 +115,13 @@ def test_syncbn_two_ranks_equal_single_device():
         # per-rank statistics (the default) are a different computation: the check above is not vacuous
         assert np.max(np.abs(per_l - single_l) / (np.abs(single_l) + 1e-6)) > 1e-3
     assert np.array_equal(res[0][1]["sync"][0], res[1][1]["sync"][0])        # both ranks report the same averaged terms
+    # K-sharded scoring == unsharded == the reference's golden ll on every rank; the ranks' draw ranges tile K
+    gs = load_golden("scoring_tiny")
+    rl = np.zeros_like(gs["rlls"])
+    for rank, out, _ in res:
+        ll_full, ll_shard, rl_shard = out["score"]
+        assert np.max(np.abs(ll_full - gs["ll"]) / (np.abs(gs["ll"]) + 1e-6)) < 1e-4
+        assert np.max(np.abs(ll_shard - gs["ll"]) / (np.abs(gs["ll"]) + 1e-6)) < 1e-4
+        assert np.max(np.abs(ll_shard - ll_full) / (np.abs(ll_full) + 1e-6)) < 1e-5
+        rl += rl_shard
+    assert np.max(np.abs(rl - gs["rlls"]) / (np.abs(gs["rlls"]) + 1e-6)) < 1e-4

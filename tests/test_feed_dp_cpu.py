@@ -76,6 +76,13 @@ def test_device_loader_index_stream_matches_torch_sampler():
     assert [shard_range(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
     val = [x.shape[0] for x, _ in DeviceBatchLoader(ds, 25, shuffle=False, drop_last=False, device="cpu")]
     assert val == [25, 25, 25, 25, 3]
+    # under data parallelism a ragged tail is trimmed to equal per-rank shares (103 = 2*50 + 3 -> ranks get 1 row each)
+    for r in range(2):
+        ld = DeviceBatchLoader(ds, 25, shuffle=False, drop_last=False, device="cpu", rank=r, world=2)
+        sizes = [x.shape[0] for x, _ in ld]
+        assert sizes == [25, 25, 1] and len(ld) == 3
+    ld = DeviceBatchLoader(ds, 103, shuffle=False, drop_last=False, device="cpu", rank=1, world=4)
+    assert [x.shape[0] for x, _ in ld] == [25] and len(ld) == 1
 
 
 def _free_port():
@@ -102,7 +109,33 @@ def _dp_worker(rank, world, port, q):
     b, e = shard_range(11, rank, world)
     ll = torch.arange(11, dtype=torch.float64)[b:e]
     tot, cnt = reduce_loglik(float(ll.sum()), ll.numel())
-    q.put((rank, arena.tolist(), scal.tolist(), tot, cnt, sync.world))
+    # Monte-Carlo draws split over the ranks: each rank folds its K-shard of the reference fixture's log-weights into
+    # a per-profile (max, sum of exp) state; two all-reduces must give the unsharded importance-weighted estimate
+    import math
+    from conftest import golden_spec, golden_state
+    from oracle import refimpl as R
+    from behavio_temporal_vae_amd.parallel import combine_lse
+    g = load_golden("scoring_tiny")
+    spec, _ = golden_spec(g)
+    sd = golden_state(g)
+    x, c, eps = (torch.from_numpy(np.array(g[k])) for k in ("x", "c", "eps"))
+    K = eps.shape[0]
+    with torch.no_grad():
+        _, rlls, _ = R.iw_loglikelihood(sd, spec, x, c, eps)
+        post = R.dist_forward(sd, "encoder", spec.enc, torch.cat((x, c), -1), False)
+        z = post["mu"] + post["sigma"] * eps
+        logw = rlls - R.normal_log_prob(z, post["mu"], post["sigma"]).sum(-1) + R.normal_log_prob(z, torch.zeros_like(z), torch.ones_like(z)).sum(-1)
+    k0, k1 = shard_range(K, rank, world)
+    mine = logw[k0:k1]
+    m_run = mine.max(0).values if k1 > k0 else torch.full((x.shape[0],), -math.inf)
+    s_run = torch.exp(mine - m_run).sum(0) if k1 > k0 else torch.zeros(x.shape[0])
+    combine_lse(m_run, s_run)
+    ll = m_run + torch.log(s_run) - math.log(K)
+    # a rank without draws (K smaller than the world) contributes nothing
+    m2 = torch.full((3,), -math.inf) if rank == 1 else torch.tensor([0.5, -2.0, 7.0])
+    s2 = torch.zeros(3) if rank == 1 else torch.tensor([1.0, 2.0, 3.0])
+    combine_lse(m2, s2)
+    q.put((rank, arena.tolist(), scal.tolist(), tot, cnt, sync.world, ll.numpy(), m2.tolist(), s2.tolist()))
     dist.destroy_process_group()
 
 
@@ -117,8 +150,11 @@ def test_data_parallel_plumbing_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, arena, scal, tot, cnt, world in res:
+    g = load_golden("scoring_tiny")
+    for rank, arena, scal, tot, cnt, world, ll, m2, s2 in res:
         assert world == 2
         assert arena == [3.0 * i for i in range(20)]          # sum over ranks of (rank+1)*i
         assert scal == [3.0, 6.0, 9.0, 12.0]
         assert tot == float(sum(range(11))) and cnt == 11
+        assert np.max(np.abs(ll - g["ll"]) / (np.abs(g["ll"]) + 1e-6)) < 1e-5      # K-sharded == the reference's ll
+        assert m2 == [0.5, -2.0, 7.0] and s2 == [1.0, 2.0, 3.0]

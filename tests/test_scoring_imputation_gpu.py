@@ -198,9 +198,9 @@ def test_pseudo_gibbs_vs_reference(dev):
     feeds = {(1, N, L): [T(e)[None] for e in g["one_eps_z"]], (N, W): [T(e) for e in g["one_eps_x"]]}
     with RandnQueue(feeds):
         cs, cm, cc, x_rec, z_rec = imputation_lib.cvae_imputation(m, xm, cond, {"c": g["c"]}, num_samples=ns, num_iter=0, warmup_steps=Tn, device="cuda:0")
-    assert np.allclose(cm.cpu().numpy(), g["one_cond_mean"], rtol=3e-4, atol=5e-5)
-    assert np.allclose(cc.cpu().numpy(), g["one_cond_cov"], rtol=3e-4, atol=5e-6)
-    assert np.allclose(cs.cpu().numpy(), g["one_cond_samples"], rtol=3e-4, atol=5e-5)
+    assert np.allclose(cm.cpu().numpy(), g["one_cond_mean"], rtol=2e-4, atol=5e-5)
+    assert np.allclose(cc.cpu().numpy(), g["one_cond_cov"], rtol=2e-4, atol=5e-6)
+    assert np.allclose(cs.cpu().numpy(), g["one_cond_samples"], rtol=2e-4, atol=5e-5)
     assert x_rec["params"]["mu"].shape == (ns, N, D) and z_rec["samples"].shape == (ns, N, L)
     # batched driver with held-out log-likelihood (batch size 6 -> ragged last batch of 4)
     bs = int(g["batch_size"])
@@ -213,8 +213,8 @@ def test_pseudo_gibbs_vs_reference(dev):
     with RandnQueue(feeds):
         ll, samples = imputation_lib.mass_cvae_imputation_with_loglikelihood(m, xm, g["target"], cond, {"c": g["c"]}, batch_size=bs, num_samples=ns,
                                                                              num_iter=0, warmup_steps=Tn, device="cuda:0")
-    assert np.allclose(samples, g["samples"], rtol=3e-4, atol=5e-5)
-    assert rel_err(ll, g["loglik"]) < 3e-4
+    assert np.allclose(samples, g["samples"], rtol=2e-4, atol=5e-5)
+    assert rel_err(ll, g["loglik"]) < 2e-4
     assert imputation_lib.pseudo_gibbs.total_time > 0 and imputation_lib.sample_conditional.total_time > 0
 
 
@@ -256,9 +256,48 @@ def test_metropolis_within_gibbs_vs_reference(dev):
     assert not us and not rq.feeds[(1, N, L)] and not rq.feeds[(N, W)]    # every recorded draw was consumed
     assert len(seen) == Tmh and np.array_equal(torch.stack(seen).numpy(), g["accepted"])
     assert x_rec is None and z_rec is None
-    assert np.allclose(cm.cpu().numpy(), g["cond_mean"], rtol=3e-4, atol=5e-5)
-    assert np.allclose(cc.cpu().numpy(), g["cond_cov"], rtol=3e-4, atol=5e-6)
-    assert np.allclose(cs.cpu().numpy(), g["cond_samples"], rtol=3e-4, atol=5e-5)
+    assert np.allclose(cm.cpu().numpy(), g["cond_mean"], rtol=2e-4, atol=5e-5)
+    assert np.allclose(cc.cpu().numpy(), g["cond_cov"], rtol=2e-4, atol=5e-6)
+    assert np.allclose(cs.cpu().numpy(), g["cond_samples"], rtol=2e-4, atol=5e-5)
+
+
+def test_normal_decoder_covariance_helpers_and_conditional(dev):
+    """GaussianNN as the decoder (src/submodels.py:120-124): ``create_covariance_matrix`` is diag(sigma^2),
+    ``get_marginal_sigmas`` is sigma, and the imputation conditional equals the general Gaussian conditioning formula
+    (src/imputation_lib.py:28-35) applied to that diagonal covariance -- mean mu_u, covariance diag(sigma_u^2) -- for a
+    non-suffix window; a short pseudo-Gibbs chain runs on it and leaves the observed entries untouched."""
+    from behavio_temporal_vae_amd import imputation_lib
+    g = load_golden("tiny_normal_2d")
+    cond = CondArray(4)
+    m = build(g, dev, cond)
+    x, c = T(g["x"]).to(dev), T(g["c"]).to(dev)
+    D = int(g["D"])
+    with torch.no_grad():
+        xd, _ = m.forward(x, c, num_mc_samples=2)
+    params = xd["params"]
+    cov = m.decoder.create_covariance_matrix(params)
+    assert cov.shape == (*params["sigma"].shape, D)
+    assert torch.equal(cov, torch.diag_embed(params["sigma"] ** 2))
+    assert torch.equal(m.decoder.get_marginal_sigmas(params), params["sigma"])
+    obs = [0, 2, 5]
+    un = [1, 3, 4]
+    p0 = {k: v[0] for k, v in params.items()}
+    mean, cc = imputation_lib.get_conditional_params(m.decoder, p0, x[:, obs], torch.tensor(obs))
+    S64 = torch.diag_embed(p0["sigma"].double() ** 2)
+    Soo, Suo, Suu = S64[:, obs][:, :, obs], S64[:, un][:, :, obs], S64[:, un][:, :, un]
+    A = Suo @ torch.linalg.inv(Soo)
+    ref_mean = p0["mu"].double()[:, un] + (A @ (x.double()[:, obs] - p0["mu"].double()[:, obs])[..., None])[..., 0]
+    ref_cov = Suu - A @ Suo.transpose(-1, -2)
+    assert torch.allclose(mean.double(), ref_mean, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(cc.double(), ref_cov, rtol=1e-6, atol=1e-9)
+    xm = g["x"].astype(np.float32).copy()
+    xm[:, un] = np.nan
+    cs, cm, cv, x_rec, z_rec = imputation_lib.cvae_imputation(m, xm, cond, {"c": g["c"]}, num_samples=2, num_iter=0, warmup_steps=3, device="cuda:0")
+    assert cs.shape == (2, xm.shape[0], 3) and cv.shape == (2, xm.shape[0], 3, 3) and torch.isfinite(cs).all()
+    assert x_rec["params"]["sigma"].shape == (2, xm.shape[0], D)
+    full = xm.copy()
+    with pytest.raises(ValueError, match="nothing to impute"):
+        imputation_lib.cvae_imputation(m, np.nan_to_num(full), cond, {"c": g["c"]}, num_samples=2, num_iter=0, warmup_steps=1, device="cuda:0")
 
 
 def test_imputation_mask_semantics(dev):
@@ -321,6 +360,41 @@ def test_training_entry_point_synthetic(dev, tmp_path):
     assert all(torch.equal(v, m2.state_dict()[k]) for k, v in sd.items())
     mk = json.load(open(os.path.join(run, "model_kwargs.json")))
     assert set(mk) == {"latent_dim", "distribution_dict", "_"}
+
+
+def test_training_entry_point_on_arrays(dev, tmp_path):
+    """``scripts/training.py --train_npz/--val_npz``: real arrays instead of the synthetic fallback, including a
+    day-before profile tag (identity) next to the calendar tags, so the condition width follows the data (2+2+24)."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("training_entry", os.path.join(ROOT, "scripts", "training.py"))
+    tr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tr)
+    rng = np.random.default_rng(5)
+
+    def split(n, path):
+        x = np.clip(rng.normal(1.0, 1.0, size=(n, 24)), -3, 5).astype(np.float32)
+        np.savez(path, X=x, cond_months=rng.integers(1, 13, size=n), cond_weekdays=rng.integers(0, 7, size=(n, 1)),
+                 cond_day_befores=np.roll(x, 1, axis=0))
+    split(1024, tmp_path / "train.npz")
+    split(300, tmp_path / "val.npz")
+    cfg = tr.load_config(os.path.join(ROOT, "config_files", "config0.json"))
+    cfg["data"]["condition_tag_list"] = ["months", "weekdays", "day_befores"]
+    cfg["model"]["latent_dim"] = 12
+    for k in ("posterior", "likelihood"):
+        cfg["model"]["distribution_dict"][k]["num_neurons"] = 64
+    cfg["train"].update({"epochs": 1, "batch_size": 256, "validation_freq": 2, "verbose_freq": 100, "num_mc_samples": 2,
+                         "validation_mc_samples": 2, "device": "cuda:0", "save_epoch_freq": 1})
+    cfg["save_dir"] = str(tmp_path)
+    model = tr.main(cfg, train_npz=str(tmp_path / "train.npz"), val_npz=str(tmp_path / "val.npz"))
+    assert model.input_dim == 24 and model.condition_dim == 28
+    sd = torch.load(os.path.join(model.log_dir, "trained_model.pt"), weights_only=True)
+    assert sd["encoder.parameterizer.block_dict.input.input_layer.0.weight"].shape == (64, 52)
+    assert int(sd["encoder.parameterizer.block_dict.mu.input_layer.2.num_batches_tracked"]) == 4
+    with pytest.raises(ValueError, match="missing condition arrays"):
+        cfg["data"]["condition_tag_list"] = ["months", "weekdays", "users"]
+        tr.main(cfg, train_npz=str(tmp_path / "train.npz"))
 
 
 def test_device_condition_feed_dirichlet(dev):
