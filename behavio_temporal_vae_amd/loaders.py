@@ -73,4 +73,7 @@ class DeviceBatchLoader:
             idx = glob[b:e]
             idx_d = idx.to(self.device)
             x = self.x.index_select(0, idx_d)
-            yield x, self.enc.encode(idx_d, self.dataset.num_samples)
+            c = self.enc.encode(idx_d, self.dataset.num_samples)
+            if c.ndim == 3 and c.shape[1] == 1:
+                c = c[:, 0].contiguous()        # one draw per item collates to [B, C]: the dataset squeezes it (src/datasets.py:22)
+            yield x, c
