@@ -76,6 +76,8 @@ _SIGS = {
     "btvae_grad_sumsq": [P, LL, P, P],
     "btvae_clip_adam_step": [P, P, P, P, LL, P, F, F, F, F, F, F, LL, P, P],
     "btvae_scale": [P, LL, F, P],
+    "btvae_adam_tick": [P, P, I, P],
+    "btvae_clip_adam_step_dev": [P, P, P, P, LL, P, P, P, P],
     "btvae_cond_mvn_sample": [P, P, P, P, ULL, P, P, P, P, I, I, I, P],
     "btvae_masked_scatter": [P, P, P, LL, P],
     "btvae_lse_over_k": [P, P, I, I, P],
@@ -89,6 +91,7 @@ _RET = {
     "btvae_bn_relu_bwd_scratch": (c_longlong, [I, I]),
     "btvae_weight_planes_elems": (c_longlong, [I, I]),
     "btvae_colsum_noalloc_max_floats": (c_longlong, []),
+    "btvae_prof_enabled": (c_int, []),
 }
 EXPORTS = sorted(list(_SIGS) + list(_RET))
 PROF_KINDS = ["gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_mvn", "bn", "mvn_rows", "reduce", "optim"]

@@ -99,6 +99,8 @@ BTVAE_API int btvae_prof_enable(int on) {
     return 0;
 }
 
+BTVAE_API int btvae_prof_enabled(void) { return g_prof_on ? 1 : 0; }
+
 // Restrict event timing to the families in kind_mask (bit k = family k) and to launches of at least min_flops FLOPs.
 // Two event records bracket every timed launch and each costs a few microseconds of stream time, so a timed region
 // that should run undisturbed selects only the launches it wants measured.  (~0u, 0) times everything (the default).

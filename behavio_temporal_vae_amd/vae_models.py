@@ -75,7 +75,8 @@ class _Fwd:
 class FusedClipAdam(torch.optim.Optimizer):
     """Adam with L2 weight decay over the model's flat arenas, fused with global-norm clipping.
     Keeps torch's two parameter groups (encoder, decoder) so LR schedulers work unchanged
-    (reference: src/vae_models.py:102-103)."""
+    (reference: src/vae_models.py:102-103).  Step count, bias corrections and hyper-parameters live in device memory
+    (``btvae_adam_tick`` / ``btvae_clip_adam_step_dev``), so a step captured in a HIP graph keeps following them."""
 
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8):
         groups = [{"params": list(model.encoder.parameters())}, {"params": list(model.decoder.parameters())}]
@@ -83,6 +84,9 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.model = model
         self._state_dev = None
         self._adam: Optional[E.ClipAdam] = None
+        self._hyper = None            # [2, 8] device floats, one row per span
+        self._steps = None            # [1] device int64 step counter
+        self._hyper_cache = [None, None]
 
     def zero_grad(self, set_to_none: bool = True):
         """Zero the gradient arena in both modes and keep the parameters' ``.grad`` views alive.  The fused
@@ -99,27 +103,80 @@ class FusedClipAdam(torch.optim.Optimizer):
             if old is not None and old.m.numel() == arena.numel():
                 self._adam.m.copy_(old.m); self._adam.v.copy_(old.v); self._adam.step_count = old.step_count
             self._state_dev = arena.device
+            self._hyper = torch.zeros(2, 8, device=arena.device)
+            self._steps = torch.full((1,), self._adam.step_count, dtype=torch.int64, device=arena.device)
+            self._hyper_cache = [None, None]
         return self._adam
+
+    def _spans(self):
+        m = self.model
+        g0, g1 = self.param_groups
+        same = all(g0[k] == g1[k] for k in ("lr", "weight_decay", "betas", "eps"))
+        n = m._arena.numel()
+        return [(0, n, g0)] if same else [(0, m._enc_span, g0), (m._enc_span, n - m._enc_span, g1)]
+
+    def refresh_hyper(self, max_norm: Optional[float] = None):
+        """Bring the device copies of (lr, betas, eps, weight decay, clipping norm) up to date with the parameter
+        groups; a host-to-device copy only when something changed (an LR scheduler).  Returns the spans."""
+        self._ensure()
+        spans = self._spans()
+        for i, (_, _, g) in enumerate(spans):
+            vals = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                    float(max_norm) if max_norm is not None else -1.0)
+            if self._hyper_cache[i] != vals:
+                self._hyper[i, :6].copy_(torch.tensor(vals, dtype=torch.float32))
+                self._hyper_cache[i] = vals
+        return spans
 
     @torch.no_grad()
     def step(self, closure=None, max_norm: Optional[float] = None):
         m = self.model
         adam = self._ensure()
-        g0, g1 = self.param_groups
-        same = all(g0[k] == g1[k] for k in ("lr", "weight_decay", "betas", "eps"))
+        spans = self.refresh_hyper(max_norm)
         n = m._arena.numel()
         adam.step_count += 1
         nv.call("btvae_grad_sumsq", nv.ptr(m._grad_arena), n, nv.ptr(adam.partials))
-        spans = [(0, n, g0)] if same else [(0, m._enc_span, g0), (m._enc_span, n - m._enc_span, g1)]
-        for off, cnt, g in spans:
-            nv.call("btvae_clip_adam_step", nv.ptr(m._arena[off:]), nv.ptr(m._grad_arena[off:]), nv.ptr(adam.m[off:]), nv.ptr(adam.v[off:]),
-                    cnt, nv.ptr(adam.partials), float(max_norm) if max_norm is not None else -1.0, float(g["lr"]), float(g["betas"][0]),
-                    float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), adam.step_count, nv.ptr(adam.norm))
+        nv.call("btvae_adam_tick", nv.ptr(self._steps), nv.ptr(self._hyper), len(spans))
+        for i, (off, cnt, _) in enumerate(spans):
+            nv.call("btvae_clip_adam_step_dev", nv.ptr(m._arena[off:]), nv.ptr(m._grad_arena[off:]), nv.ptr(adam.m[off:]), nv.ptr(adam.v[off:]),
+                    cnt, nv.ptr(adam.partials), nv.ptr(self._hyper[i]), nv.ptr(adam.norm))
         return None
 
     @property
     def last_grad_norm(self) -> torch.Tensor:
         return self._ensure().norm
+
+
+STEP_GRAPH_MAX_ROWS = 32768     # S*B up to which train_core is replayed from a HIP graph (launch-bound below, kernel-bound above)
+STEP_GRAPH_WARMUP = 2           # eager steps of one shape before it is captured
+
+
+class _StepGraph:
+    """One ``train_core`` step (forward, ELBO, backward, clip + Adam) captured as a HIP graph.
+
+    The step is ~160 short launches; at the batch size config0.json ships (1024) the host cannot issue them as fast as
+    the GPU retires them.  Capturing records the launches once -- every device buffer they touch comes from the graph's
+    own memory pool or is persistent (arenas, optimiser state, workspaces, which the object keeps alive) -- and each
+    later step is one graph launch after copying the batch into the captured input buffers.  The latent noise comes
+    from torch's CUDA generator, which advances its Philox offset per replay; step count, bias corrections and learning
+    rate are read from device memory by the optimiser kernel."""
+
+    def __init__(self, model, optim, x, c, eps=None):
+        self.x, self.c = x.clone(), c.clone()
+        self.eps = eps.clone() if eps is not None else None       # injected noise (tests): a captured input like x and c
+        self.keep = (list(E.WS.bufs.values()), optim, optim._ensure(), optim._hyper, optim._steps)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = model._train_step_eager(self.x, self.c, optim, eps=self.eps)
+        self.keep = self.keep + (list(E.WS.bufs.values()),)
+
+    def run(self, x, c, eps=None):
+        self.x.copy_(x)
+        self.c.copy_(c)
+        if self.eps is not None:
+            self.eps.copy_(eps.reshape(self.eps.shape))
+        self.graph.replay()
+        return self.out.clone()
 
 
 class VAE(torch.nn.Module):
@@ -459,11 +516,83 @@ class VAE(torch.nn.Module):
                 torch.nn.utils.clip_grad_norm_(self.parameters(), **ck)
             optim.step()
 
-    def _train_step(self, x, c, optim, eps=None):
+    def _train_step_eager(self, x, c, optim, eps=None):
         fw = self._run_forward(x, c, self.train_kwargs["num_mc_samples"], eps=eps, tape=True)
         out = self._loss_and_backward(fw, x, self.train_kwargs["beta"])
         out = self._dp_finish(out)
         self._optim_step(optim)
+        return out
+
+    def _graph_key(self, x, c, optim, eps):
+        """Key of the captured step this call could replay, or None when the call has to run eagerly:
+        data parallelism, dropout (its seeds are drawn on the host), sampled 3-D conditions, per-launch event timing, a
+        stock torch optimiser, clipping options the fused step does not cover, or more rows than the launch-bound regime."""
+        mode = os.environ.get("BTVAE_STEP_GRAPH", "auto")
+        if mode == "0" or self._dp_world > 1 or E.BN_SYNC is not None or not self.training:
+            return None
+        if eps is not None and (eps.dtype != torch.float32 or eps.device != x.device):
+            return None
+        if not isinstance(optim, FusedClipAdam) or c is None or c.ndim != 2 or x.dtype != torch.float32 or c.dtype != torch.float32:
+            return None
+        if not x.is_cuda or x.device != self._arena.device or c.device != x.device:
+            return None
+        tk = self.train_kwargs
+        clip = tk.get("gradient_clipping", False)
+        ck = dict(tk.get("gradient_clipping_kwargs", {"max_norm": 1.0})) if clip else {}
+        if clip and not (set(ck) <= {"max_norm"} or (set(ck) <= {"max_norm", "norm_type"} and float(ck.get("norm_type", 2.0)) == 2.0)):
+            return None
+        S = int(tk["num_mc_samples"])
+        if mode != "1" and S * x.shape[0] > STEP_GRAPH_MAX_ROWS:
+            return None
+        if any(u.dropout_p > 0.0 for net in (self.encoder, self.decoder) for u in net.plan().trunk + [u for h in net.plan().heads.values() for u in h]):
+            return None
+        if nv.lib().btvae_prof_enabled():
+            return None
+        return (tuple(x.shape), tuple(c.shape), S, float(tk["beta"]), self.gemm_precision, id(optim), self._arena.data_ptr(),
+                ck.get("max_norm") if clip else None, E.FOLD_BN_INTO_CONSUMER, E.BWD_SUMS_FROM_CONSUMERS,
+                None if eps is None else tuple(eps.shape))
+
+    def _train_step(self, x, c, optim, eps=None):
+        key = self._graph_key(x, c, optim, eps)
+        out = None
+        if key is not None:
+            graphs = self.__dict__.setdefault("_step_graphs", {})
+            seen = self.__dict__.setdefault("_step_seen", {})
+            g = graphs.get(key)
+            if g is None and seen.get(key, 0) >= STEP_GRAPH_WARMUP and not self.__dict__.get("_step_graph_failed"):
+                self._check_arena()
+                optim.refresh_hyper(key[7])
+                counters = ([getattr(net.plan(), "nbt_pending", 0) for net in (self.encoder, self.decoder)], optim._ensure().step_count)
+                try:
+                    g = _StepGraph(self, optim, self._prep(x, "inputs"), self._prep(c, "conditions"),
+                                   None if eps is None else self._prep(eps, "eps"))
+                except Exception as exc:          # leave the eager path in charge for the rest of the run
+                    self.__dict__["_step_graph_failed"] = True
+                    for net, v in zip((self.encoder, self.decoder), counters[0]):
+                        net.plan().nbt_pending = v
+                    optim._ensure().step_count = counters[1]
+                    import warnings
+                    warnings.warn(f"capturing the training step as a HIP graph failed ({exc}); continuing without it")
+                    g = None
+                else:
+                    if len(graphs) >= 2:
+                        graphs.clear()
+                    graphs[key] = g
+                    # capturing recorded the launches without running them, but the host-side counters of that pass
+                    # (BatchNorm batches, optimiser steps) already moved: put them back, the replay below counts itself
+                    for net, v in zip((self.encoder, self.decoder), counters[0]):
+                        net.plan().nbt_pending = v
+                    optim._ensure().step_count = counters[1]
+            seen[key] = seen.get(key, 0) + 1
+            if g is not None:
+                optim.refresh_hyper(key[7])
+                out = g.run(x, c, eps)
+                for net in (self.encoder, self.decoder):
+                    plan = net.plan()
+                    plan.nbt_pending = getattr(plan, "nbt_pending", 0) + 1
+                optim._ensure().step_count += 1
+        if out is None:
+            out = self._train_step_eager(x, c, optim, eps=eps)
         return {"loss": out[0], "elbo": out[1], "rll": out[2], "kl": out[3]}
 
     def train_core(self, inputs, optim, **_):

@@ -23,6 +23,7 @@ int btvae_init(int device);
 /* Event timing per kernel family (0 gemm_fwd, 1 gemm_dgrad, 2 gemm_wgrad, 3 gemm_mvn, 4 bn, 5 mvn_rows,
  * 6 reduce, 7 optim); collect after a device synchronisation into arrays of 8. */
 int btvae_prof_enable(int on);
+int btvae_prof_enabled(void);
 /* Time only the families in kind_mask (bit k = family k) and launches of at least min_flops; (~0u, 0) = everything. */
 int btvae_prof_filter(unsigned kind_mask, double min_flops);
 int btvae_prof_collect(double* ms, double* flops, double* bytes, long long* launches, int n);
@@ -222,6 +223,13 @@ int btvae_grad_sumsq(const float* g, long long n, double* partials512, void* str
 int btvae_clip_adam_step(float* p, const float* g, float* m, float* v, long long n, const double* partials512,
                          float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                          long long step, float* norm_out, void* stream);
+/* The same step with its scalars in device memory, so that a launch replayed from a HIP graph follows the learning rate
+ * and the step count: `step` is an int64 counter on the device, hyper = [lr, beta1, beta2, eps, weight_decay, max_norm
+ * (<= 0: no clipping), bc1, sqrt(bc2)].  btvae_adam_tick adds one to the counter and rewrites bc1 = 1 - beta1^step and
+ * sqrt(bc2) = sqrt(1 - beta2^step) in `rows` consecutive hyper blocks; the caller writes hyper[0..5] of each. */
+int btvae_adam_tick(long long* step, float* hyper, int rows, void* stream);
+int btvae_clip_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, const double* partials512,
+                             const float* hyper, float* norm_out, void* stream);
 int btvae_scale(float* x, long long n, float a, void* stream);
 
 /* ---- conditional imputation (src/imputation_lib.py:16-57,92,230-231) ---- */

@@ -28,6 +28,8 @@ def main():
     X = torch.randn(M, K, device=dev, generator=g)
     W = torch.randn(N, K, device=dev, generator=g) * 0.03
     b = torch.randn(N, device=dev, generator=g)
+    if os.environ.get("BTVAE_BENCH_ZERO"):          # all-zero operands: the rate the instruction stream allows when no datapath toggles
+        X.zero_(); W.zero_()
     Y = torch.empty(M, N, device=dev)
     part = torch.empty((M + 127) // 128, 2, N, device=dev)
     dX = torch.empty(M, K, device=dev)
