@@ -158,17 +158,11 @@ __global__ __launch_bounds__(256, BTVAE_GEMM_MINWG) void gemm_f32_mfma(const Gem
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, lh = lane >> 5;
 
-    // Workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of tiles so
-    // the tiles that share an A row panel meet in one L2 (bijective for any tile count).
-    int bid = blockIdx.x;
-    {
-        const int nwg = p.tiles_m * p.tiles_n;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    int zz;
+    const int bid = wg_tile(p, zz);
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int kbeg = blockIdx.z * p.kchunk;
+    const int kbeg = zz * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
 
@@ -259,7 +253,7 @@ __global__ __launch_bounds__(256, BTVAE_GEMM_MINWG) void gemm_f32_mfma(const Gem
         __syncthreads();
     }
 
-    gemm_epilogue<EPI>(p, acc, &smem[0][0][0], m0, n0, tile_m);   // the k-loop's last barrier has retired all tile reads
+    gemm_epilogue<EPI>(p, acc, &smem[0][0][0], m0, n0, tile_m, zz);   // the k-loop's last barrier has retired all tile reads
 }
 
 // sum of the z slabs of element i; four independent partial sums keep several loads in flight

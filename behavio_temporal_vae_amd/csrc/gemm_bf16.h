@@ -104,15 +104,11 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_mfma(const GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
 
-    int bid = blockIdx.x;
-    {
-        const int nwg = p.tiles_m * p.tiles_n;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    int zz;
+    const int bid = wg_tile(p, zz);
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int kbeg = blockIdx.z * p.kchunk;
+    const int kbeg = zz * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int nk = kend > kbeg ? (kend - kbeg + HBK - 1) / HBK : 0;
 
@@ -173,7 +169,7 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_mfma(const GemmArgs p) {
         __syncthreads();
     }
 
-    gemm_epilogue<EPI>(p, acc, reinterpret_cast<float*>(&smem[0][0][0]), m0, n0, tile_m);
+    gemm_epilogue<EPI>(p, acc, reinterpret_cast<float*>(&smem[0][0][0]), m0, n0, tile_m, zz);
 }
 
 }  // namespace btvae_gemm

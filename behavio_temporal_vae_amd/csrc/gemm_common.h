@@ -45,6 +45,28 @@ struct GemmArgs {
     int tiles_m, tiles_n;
 };
 
+// Which output tile (returned, row-major tile index) and which reduction split `zz` this workgroup computes.  Workgroups
+// are dealt round-robin over the 8 XCDs in dispatch order (x fastest, then z), and each XCD has its own L2:
+//  * one split: every XCD gets a contiguous run of tiles, so the tiles that share an A row panel meet in one L2;
+//  * a reduction split over a multiple of 8 slabs (the weight gradients): every XCD gets whole splits -- all output
+//    tiles of gridDim.z / 8 consecutive reduction ranges -- so each operand row is fetched into exactly one L2 and
+//    reused there by all the tiles, instead of one operand being streamed through all eight (4.6 x the algorithmic
+//    bytes from beyond L2 at N = K = 1000, M = 65536);
+//  * any other split count: tiles as in the first case, splits as dispatched.
+__device__ __forceinline__ int wg_tile(const GemmArgs& p, int& zz) {
+    const int T = p.tiles_m * p.tiles_n, nz = (int)gridDim.z;
+    if (nz > 1 && (nz & 7) == 0) {
+        const int L = (int)blockIdx.x + T * (int)blockIdx.z;
+        const int xcd = L & 7, idx = L >> 3;
+        zz = xcd * (nz >> 3) + idx / T;
+        return idx % T;
+    }
+    zz = (int)blockIdx.z;
+    const int bid = (int)blockIdx.x;
+    const int q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 __device__ __forceinline__ float softplus5(float x) { return x > 5.f ? x : log1pf(expf(x)); }
 
 // head non-linearity of one raw output: value and d value / d raw  (act 0: clamp, 1: clamp(softplus), 2: clamp(relu))
@@ -65,7 +87,7 @@ __device__ __forceinline__ void head_value(const GemmArgs& p, float raw, float& 
 
 // `red` is LDS scratch of at least 6*128 floats that no wave still reads as a tile.
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x16 (&acc)[2][2], float* red, int m0, int n0, int tile_m) {
+__device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x16 (&acc)[2][2], float* red, int m0, int n0, int tile_m, int zz) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -81,7 +103,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x16 (
         colv[cb][1] = (EPI == EPI_RELU_AFFINE && ok && p.scale) ? p.scale[col] : 1.f;
         colv[cb][2] = (EPI == EPI_RELU_AFFINE && ok && p.shift) ? p.shift[col] : 0.f;
     }
-    float* Cz = p.C + (size_t)blockIdx.z * p.slab_stride;
+    float* Cz = p.C + (size_t)zz * p.slab_stride;
 
     float st_n[2], st_mean[2], st_m2[2];   // EPI_RELU_STATS: this lane's (count, mean, M2) per column block
 #pragma unroll
@@ -204,7 +226,7 @@ __device__ __forceinline__ float4 ld4(const float* q) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* q, const float4 v) { *reinterpret_cast<float4*>(q) = v; }
 
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[2][2], float* lds, int m0, int n0, int tile_m) {
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[2][2], float* lds, int m0, int n0, int tile_m, int zz) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -218,7 +240,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
         sc[cb] = (EPI == EPI_RELU_AFFINE && ok && p.scale) ? p.scale[col] : 1.f;
         sh[cb] = (EPI == EPI_RELU_AFFINE && ok && p.shift) ? p.shift[col] : 0.f;
     }
-    float* Cz = p.C + (size_t)blockIdx.z * p.slab_stride;
+    float* Cz = p.C + (size_t)zz * p.slab_stride;
     // column statistics (EPI_RELU_STATS): shifted sums per lane over its rows of both halves
     float st_k[2] = {0.f, 0.f}, st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f}, st_c[2] = {0.f, 0.f};
     bool have[2] = {false, false};
@@ -461,9 +483,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
 
 // `lds`: at least 36 KiB of LDS that no wave still reads as a tile
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2][2], float* lds, int m0, int n0, int tile_m) {
-    if (p.c_vec) gemm_epilogue_staged<EPI>(p, acc, lds, m0, n0, tile_m);
-    else         gemm_epilogue_direct<EPI>(p, acc, lds, m0, n0, tile_m);
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2][2], float* lds, int m0, int n0, int tile_m, int zz) {
+    if (p.c_vec) gemm_epilogue_staged<EPI>(p, acc, lds, m0, n0, tile_m, zz);
+    else         gemm_epilogue_direct<EPI>(p, acc, lds, m0, n0, tile_m, zz);
 }
 
 }  // namespace btvae_gemm
