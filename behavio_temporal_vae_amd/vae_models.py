@@ -803,6 +803,15 @@ class CVAE(VAE):
     def reconstruct(self, inputs, conditions, num_mc_samples=1):
         return self.forward(inputs=inputs, conditions=conditions, num_mc_samples=num_mc_samples)
 
+    @torch.no_grad()
+    def loglikelihood(self, inputs, conditions, num_mc_samples=1):
+        """Importance-weighted log-likelihood per profile, -log K + logsumexp_k(log p(x|z_k,c) + log p(z_k) - log q(z_k|x,c)).
+        The reference's method of this name cannot run (``torch.logsumexp`` without ``dim``, src/vae_models.py:315); this
+        returns what its formula describes, the quantity ``testing_lib.mass_loglikelihood`` computes (src/testing_lib.py:14)."""
+        from .testing_lib import iw_loglikelihood_device
+        ll, _, _ = iw_loglikelihood_device(self, inputs, conditions, num_mc_samples, min(int(num_mc_samples), 100))
+        return ll
+
     def train_core(self, inputs, optim, **_):
         x, c = inputs
         return self._train_step(x, c, optim)

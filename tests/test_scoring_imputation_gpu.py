@@ -102,6 +102,11 @@ def test_iw_scoring_vs_reference(dev):
     assert rel_err(rl3.numpy(), g["rlls"]) < 1e-4
     assert x_rec["params"]["mu"].shape == (K, N, int(g["D"])) and x_rec["params"]["sigma"].shape == (K, N, 9)
     assert z_rec["samples"].shape == (K, N, L) and z_rec["params"]["mu"].shape == (N, L)
+    # the model's own loglikelihood method (one chunk of K draws)
+    m.to(dev)
+    with RandnQueue({(K, N, L): [T(g["eps"])]}):
+        ll4 = m.loglikelihood(x, c, num_mc_samples=K)
+    assert rel_err(ll4.cpu().numpy(), g["ll"]) < 1e-4
     # prior-sample scoring (model.sample + decoder.log_likelihood)
     m.to(dev)
     z = T(g["prior_z"])
