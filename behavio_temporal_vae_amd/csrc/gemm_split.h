@@ -171,6 +171,10 @@ __device__ __forceinline__ int s_frag_off(int blk, int lane) {
 #ifndef BTVAE_SPLIT_VPM_PRE
 #define BTVAE_SPLIT_VPM_PRE 5     // the same with a pre-split B operand (half the split arithmetic)
 #endif
+#ifndef BTVAE_SPLIT_ORDER
+#define BTVAE_SPLIT_ORDER 1       // issue order of the six matrix instructions of a product: 0 per accumulator, 1 A-operand stationary
+                                  // (+0.5-1 % at the held clock: fewer operand-input transitions; one operand changing per instruction: no gain)
+#endif
 #ifndef BTVAE_SPLIT_WG
 #define BTVAE_SPLIT_WG 2          // workgroups per CU the register budget is set for
 #endif
@@ -252,6 +256,23 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
                 a[pl][i] = s_frag<AL>(As + pl * PLA, oa[i]);
                 b[pl][i] = s_frag<BL>(Bs + pl * PLB, ob[i]);
             }
+#if BTVAE_SPLIT_ORDER == 1
+        // operand-stationary order: the A operand stays the same over consecutive matrix instructions (6, 4, 2 of them),
+        // small terms first within what that allows
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int pb = 1; pb >= 0; --pb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[pb][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int pb = 2; pb >= 0; --pb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[pb][j], acc[i][j], 0, 0, 0);
+        }
+#else
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -263,6 +284,7 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
             }
+#endif
     };
 
     // Iteration t: multiply tile t from LDS, publish tile t+1 from its register set, refill that set with tile
