@@ -24,6 +24,10 @@ def main():
         nv.set_gemm_precision(os.environ["BTVAE_BENCH_PREC"])
     M = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
     N = K = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
+    if os.environ.get("BTVAE_BENCH_K"):             # reduction length on its own: forward products only (the other entries
+        K = int(os.environ["BTVAE_BENCH_K"])        # of `ops` assume N == K in how their buffers are sized and are not run)
+        if which not in ("fwd", "fwd_pw"):
+            raise SystemExit("BTVAE_BENCH_K applies to fwd / fwd_pw only")
     g = torch.Generator(device=dev).manual_seed(0)
     X = torch.randn(M, K, device=dev, generator=g)
     W = torch.randn(N, K, device=dev, generator=g) * 0.03
@@ -31,7 +35,7 @@ def main():
     if os.environ.get("BTVAE_BENCH_ZERO"):          # all-zero operands: the rate the instruction stream allows when no datapath toggles
         X.zero_(); W.zero_()
     Y = torch.empty(M, N, device=dev)
-    part = torch.empty((M + 127) // 128, 2, N, device=dev)
+    part = torch.empty((M + 127) // 128, 2, max(N, K), device=dev)
     dX = torch.empty(M, K, device=dev)
     dW = torch.empty(N, K, device=dev)
     ws = torch.empty(32 * 1024 * 1024, device=dev)
@@ -61,6 +65,8 @@ def main():
         "dgrad": lambda: nv.call("btvae_linear_dgrad", P(Y), P(W), None, P(dX), K, M, N, K),
         "wgrad": lambda: nv.call("btvae_linear_wgrad", P(Y), P(X), K, P(dW), P(ws), ws.numel(), M, N, K, 0),
     }
+    if N != K:
+        ops = {k: v for k, v in ops.items() if k in ("fwd", "fwd_pw")}
     for _ in range(15):          # let the clock settle before anything is timed
         for fn in ops.values():
             fn()
