@@ -297,6 +297,13 @@ class VAE(torch.nn.Module):
         self._flush_bn_counters()
         return super().state_dict(*a, **k)
 
+    def __getstate__(self):
+        # captured step graphs hold device resources of this process: they are rebuilt on demand, never copied or pickled
+        state = dict(self.__dict__)
+        for k in ("_step_graphs", "_step_seen", "_step_graph_failed"):
+            state.pop(k, None)
+        return state
+
     # ------------------------------------------------------------------ forward
     def _prep(self, t: torch.Tensor, name: str) -> torch.Tensor:
         if t.device != self._arena.device:
@@ -544,7 +551,12 @@ class VAE(torch.nn.Module):
         S = int(tk["num_mc_samples"])
         if mode != "1" and S * x.shape[0] > STEP_GRAPH_MAX_ROWS:
             return None
-        if any(u.dropout_p > 0.0 for net in (self.encoder, self.decoder) for u in net.plan().trunk + [u for h in net.plan().heads.values() for u in h]):
+        has_dropout = self.__dict__.get("_has_dropout")
+        if has_dropout is None:
+            has_dropout = any(u.dropout_p > 0.0 for net in (self.encoder, self.decoder)
+                              for u in net.plan().trunk + [u for h in net.plan().heads.values() for u in h])
+            self.__dict__["_has_dropout"] = has_dropout
+        if has_dropout:
             return None
         if nv.lib().btvae_prof_enabled():
             return None
