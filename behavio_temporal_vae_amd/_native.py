@@ -32,6 +32,9 @@ _SIGS = {
     "btvae_linear_relu_affine_fwd_pw": [P, I, P, P, P, P, P, P, P, I, I, I, P],
     "btvae_weight_planes": [P, I, I, I, P, I, P],
     "btvae_weight_planes_multi": [P, P, P, P, P, I, P],
+    "btvae_weight_planes_f16": [P, I, I, I, P, I, P, P],
+    "btvae_weight_planes_f16_multi": [P, P, P, P, P, P, I, P],
+    "btvae_absmax": [P, LL, P, P],
     "btvae_linear_head_fwd": [P, I, P, P, I, F, F, P, P, P, I, I, I, P],
     "btvae_linear_dgrad": [P, P, P, P, I, I, I, I, P],
     "btvae_linear_dgrad_pw": [P, P, P, P, P, I, I, I, I, P],
@@ -92,6 +95,7 @@ _RET = {
     "btvae_weight_planes_elems": (c_longlong, [I, I]),
     "btvae_colsum_noalloc_max_floats": (c_longlong, []),
     "btvae_prof_enabled": (c_int, []),
+    "btvae_gemm_operand_maxima": (c_int, [P, P]),
 }
 EXPORTS = sorted(list(_SIGS) + list(_RET))
 PROF_KINDS = ["gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_mvn", "bn", "mvn_rows", "reduce", "optim"]
@@ -175,13 +179,16 @@ def f32(t, name="tensor"):
     return t.contiguous()
 
 
-GEMM_PRECISIONS = {"fp32": 0, "bf16": 1, "fp32_split": 2}
+GEMM_PRECISIONS = {"fp32": 0, "bf16": 1, "fp32_split": 2, "fp32_split2": 3}
 
 
 def set_gemm_precision(name: str):
     """Operand precision of the Linear-layer products, process-wide: ``"fp32_split"`` (what models ask for unless
     configured otherwise: fp32-accurate products as three-way bf16 splits on the bf16 matrix pipe), ``"fp32"`` (the fp32
-    MFMA instruction; the library's own start-up mode) or ``"bf16"`` (bf16-rounded operands, fp32 accumulation)."""
+    MFMA instruction; the library's own start-up mode), ``"bf16"`` (bf16-rounded operands, fp32 accumulation) or
+    ``"fp32_split2"`` (as ``"fp32_split"``, but the Linear products whose callers supply their operands' absolute maxima
+    run on two fp16 pieces per value, scaled per tensor: three matrix instructions per product instead of six, element
+    errors ~2^-22 relative to the tensor's largest magnitude instead of to the element)."""
     if name not in GEMM_PRECISIONS:
         raise ValueError(f"unknown GEMM precision {name!r}; choose from {sorted(GEMM_PRECISIONS)}")
     if lib().btvae_set_gemm_precision(GEMM_PRECISIONS[name]) != 0:

@@ -343,8 +343,13 @@ __global__ __launch_bounds__(256) void cols_finalize_kernel(const float* __restr
 // element (row r, k) of a block at s_off(r, k >> 3) + (k & 7); image D (W rows = reduction index; the dX products):
 // blocks [ceil(C/128)][ceil(R/16)][3][2048], element (k row, column) at 128 * row + column.  Zero padded.
 // One thread per 8 consecutive elements of a row, first of image F, then of image D (`which`: bit 0 = F, bit 1 = D).
+// `amax` null: three bf16 pieces per element (blocks of 3 planes).  Otherwise two fp16 pieces of the element times the
+// power-of-two scale that *amax (the matrix's absolute maximum) selects, in blocks of 2 planes; image D still starts where
+// it would with three.
 __device__ __forceinline__ void weight_planes_body(const float* __restrict__ W, int ldw, int R, int C,
-                                                   unsigned short* __restrict__ planes, int which, bool vec, size_t idx) {
+                                                   unsigned short* __restrict__ planes, int which, bool vec, size_t idx,
+                                                   const float* __restrict__ amax = nullptr) {
+    const int npl = amax ? 2 : 3;
     const int FT = (R + 127) / 128, FK = (C + 15) / 16, DT = (C + 127) / 128, DK = (R + 15) / 16;
     const size_t nF = (size_t)FT * FK * 256, nD = (size_t)DT * DK * 256;
     if (!(which & 1)) idx += nF;
@@ -355,13 +360,13 @@ __device__ __forceinline__ void weight_planes_body(const float* __restrict__ W, 
         const size_t blk = idx >> 8; const int t = (int)(idx & 255);
         const int row = t >> 1, half = t & 1;
         r = (int)(blk / FK) * 128 + row; c0 = (int)(blk % FK) * 16 + half * 8;
-        dst = planes + blk * (3 * SPLANE) + s_off(row, half);
+        dst = planes + blk * (npl * SPLANE) + s_off(row, half);
     } else {
         idx -= nF;
         const size_t blk = idx >> 8; const int t = (int)(idx & 255);
         const int row = t >> 4, seg = t & 15;
         r = (int)(blk % DK) * 16 + row; c0 = (int)(blk / DK) * 128 + seg * 8;
-        dst = planes + nF * 24 + blk * (3 * SPLANE) + row * 128 + seg * 8;
+        dst = planes + nF * 24 + blk * (npl * SPLANE) + row * 128 + seg * 8;
     }
     float v[8];
     if (vec && r < R && c0 + 7 < C) {
@@ -373,6 +378,14 @@ __device__ __forceinline__ void weight_planes_body(const float* __restrict__ W, 
         for (int i = 0; i < 8; ++i) v[i] = (r < R && c0 + i < C) ? W[(size_t)r * ldw + c0 + i] : 0.f;
     }
     unsigned H[4], M[4], L[4];
+    if (amax) {
+        const float sc = scale_for(*amax);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split2h(v[2 * i], v[2 * i + 1], sc, H[i], M[i]);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(H[0], H[1], H[2], H[3]);
+        *reinterpret_cast<uint4*>(dst + SPLANE) = make_uint4(M[0], M[1], M[2], M[3]);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) split2(v[2 * i], v[2 * i + 1], H[i], M[i], L[i]);
     *reinterpret_cast<uint4*>(dst) = make_uint4(H[0], H[1], H[2], H[3]);
@@ -381,23 +394,56 @@ __device__ __forceinline__ void weight_planes_body(const float* __restrict__ W, 
 }
 
 __global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restrict__ W, int ldw, int R, int C,
-                                                            unsigned short* __restrict__ planes, int which, int vec) {
-    weight_planes_body(W, ldw, R, C, planes, which, vec != 0, (size_t)blockIdx.x * 256 + threadIdx.x);
+                                                            unsigned short* __restrict__ planes, int which, int vec,
+                                                            const float* __restrict__ amax) {
+    weight_planes_body(W, ldw, R, C, planes, which, vec != 0, (size_t)blockIdx.x * 256 + threadIdx.x, amax);
 }
 
 // several matrices in one launch: blockIdx.y selects the entry
 constexpr int PLANES_BATCH = 16;
 struct PlanesBatch {
-    const float* W[PLANES_BATCH]; unsigned short* planes[PLANES_BATCH];
+    const float* W[PLANES_BATCH]; unsigned short* planes[PLANES_BATCH]; const float* amax[PLANES_BATCH];
     int ldw[PLANES_BATCH], R[PLANES_BATCH], C[PLANES_BATCH], which[PLANES_BATCH], vec[PLANES_BATCH];
 };
 __global__ __launch_bounds__(256) void weight_planes_multi_kernel(const PlanesBatch b) {
     const int e = blockIdx.y;
-    weight_planes_body(b.W[e], b.ldw[e], b.R[e], b.C[e], b.planes[e], b.which[e], b.vec[e] != 0, (size_t)blockIdx.x * 256 + threadIdx.x);
+    weight_planes_body(b.W[e], b.ldw[e], b.R[e], b.C[e], b.planes[e], b.which[e], b.vec[e] != 0, (size_t)blockIdx.x * 256 + threadIdx.x, b.amax[e]);
 }
 
 inline long long planes_f_elems(int N, int K) { return (long long)((N + 127) / 128) * ((K + 15) / 16) * 3 * SPLANE; }
 inline long long planes_d_elems(int N, int K) { return (long long)((K + 127) / 128) * ((N + 15) / 16) * 3 * SPLANE; }
+
+// absolute maximum of n floats folded into *out with an integer atomic maximum on the bit pattern (non-negative floats
+// order like their bits); *out must hold a non-negative value -- zero, or a maximum to extend -- beforehand.  NaNs are
+// skipped (fmaxf), infinities kept.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+    const size_t n4 = n >> 2;
+    float m = 0.f;
+    const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (vec) {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
+
+// which kernels exist with two fp16 pieces per operand value: the Linear layers' products
+template <int AL, int BL, int EPI> constexpr bool has_twopiece() {
+    return (AL == LAY_K && BL == LAY_K && (EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE)) ||
+           (AL == LAY_K && BL == LAY_M && (EPI == EPI_PLAIN || EPI == EPI_BNBWD || EPI == EPI_GSTATS)) ||
+           (AL == LAY_M && BL == LAY_M && EPI == EPI_PLAIN);
+}
+
+// absolute maxima of the operands of the next product launched from this thread (two-piece mode); consumed by it
+thread_local const float* t_amax_a = nullptr;
+thread_local const float* t_amax_b = nullptr;
 
 // which kernels exist with a pre-split B operand: the Linear forward products and the dX products
 template <int AL, int BL, int EPI> constexpr bool has_presplit() {
@@ -407,12 +453,16 @@ template <int AL, int BL, int EPI> constexpr bool has_presplit() {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-std::atomic<int> g_precision{0};   // 0: fp32 MFMA, 1: bf16 operands, 2: fp32 operands as three bf16 pieces (Linear layers only)
+// 0: fp32 MFMA, 1: bf16 operands, 2: fp32 operands as three bf16 pieces, 3: as 2 but two scaled fp16 pieces in the
+// products that were given their operands' absolute maxima
+std::atomic<int> g_precision{0};
 
 // `reduced_ok`: this product may run with bf16-ROUNDED operands when that mode is selected (Linear fwd/dgrad/wgrad);
 // the covariance products of the likelihood never do.  The split mode is fp32-accurate and applies to every product.  On return a.kchunk holds the split length used.
 template <int AL, int BL, int EPI>
 int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduced_ok = false) {
+    a.amax_a = t_amax_a; a.amax_b = t_amax_b;
+    t_amax_a = t_amax_b = nullptr;
     BTVAE_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "%s: empty problem M=%d N=%d K=%d", what, a.M, a.N, a.K);
     BTVAE_REQUIRE(a.A && a.B && a.C, "%s: null operand", what);
     BTVAE_REQUIRE(a.ldc >= a.N, "%s: ldc %d < N %d", what, a.ldc, a.N);
@@ -429,7 +479,9 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     if (splits < 1) splits = 1;
     const int prec = g_precision.load(std::memory_order_relaxed);
     const bool bf16 = reduced_ok && prec == 1 && a.a_vec && a.b_vec;
-    const bool split = prec == 2 && a.a_vec && a.b_vec;          // fp32-accurate: every product may use it
+    const bool split = prec >= 2 && a.a_vec && a.b_vec;          // fp32-accurate: every product may use it
+    const bool two = split && prec == 3 && has_twopiece<AL, BL, EPI>() && a.amax_a && a.amax_b;
+    if (prec == 3 && !two) a.Bp = nullptr;                       // planes made in this mode hold fp16 pieces
     const int bk = bf16 ? HBK : split ? SBK : BK;
     a.kchunk = (((a.K + splits - 1) / splits) + bk - 1) / bk * bk;
     splits = (a.K + a.kchunk - 1) / a.kchunk;
@@ -438,7 +490,14 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     else if (split) {
         bool pre = false;
         if constexpr (has_presplit<AL, BL, EPI>()) {
-            if (a.Bp) { pre = true; hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI, true>), grid, dim3(256), 0, s, a); }
+            if (a.Bp) {
+                pre = true;
+                if (two) hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI, true, 2>), grid, dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI, true>), grid, dim3(256), 0, s, a);
+            }
+        }
+        if constexpr (has_twopiece<AL, BL, EPI>()) {
+            if (!pre && two) { pre = true; hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI, false, 2>), grid, dim3(256), 0, s, a); }
         }
         if (!pre) hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI>), grid, dim3(256), 0, s, a);
     }
@@ -467,7 +526,7 @@ using namespace btvae;
 // rounded to bf16 on the way into LDS, fp32 accumulation.  Process-wide; products whose operands are not 16-byte
 // aligned with leading dimensions that are multiples of 4 stay on the fp32 kernel either way.
 BTVAE_API int btvae_set_gemm_precision(int mode) {
-    BTVAE_REQUIRE(mode >= 0 && mode <= 2, "set_gemm_precision: unknown mode %d (0 = fp32 MFMA, 1 = bf16 operands, 2 = fp32 as split bf16)", mode);
+    BTVAE_REQUIRE(mode >= 0 && mode <= 3, "set_gemm_precision: unknown mode %d (0 = fp32 MFMA, 1 = bf16 operands, 2 = fp32 as three bf16 pieces, 3 = as two scaled fp16 pieces)", mode);
     g_precision.store(mode, std::memory_order_relaxed);
     return 0;
 }
@@ -484,7 +543,7 @@ BTVAE_API long long btvae_weight_planes_elems(int N, int K) {
     return planes_f_elems(N, K) + planes_d_elems(N, K);
 }
 
-BTVAE_API int btvae_weight_planes(const float* W, int ldw, int N, int K, void* planes, int which, void* stream) {
+static int weight_planes_impl(const float* W, int ldw, int N, int K, void* planes, int which, const float* amax, void* stream) {
     BTVAE_REQUIRE(W && planes, "weight_planes: null pointer");
     BTVAE_REQUIRE(which >= 1 && which <= 3, "weight_planes: which = %d (1: forward image, 2: dX image, 3: both)", which);
     BTVAE_REQUIRE(N > 0 && K > 0 && ldw >= K, "weight_planes: bad shape N=%d K=%d ldw=%d", N, K, ldw);
@@ -492,14 +551,40 @@ BTVAE_API int btvae_weight_planes(const float* W, int ldw, int N, int K, void* p
     const size_t threads = (size_t)(((which & 1) ? planes_f_elems(N, K) : 0) + ((which & 2) ? planes_d_elems(N, K) : 0)) / 24;
     const dim3 grid((unsigned)((threads + 255) / 256));
     hipLaunchKernelGGL(weight_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, (unsigned short*)planes, which,
-                       (ldw % 4 == 0 && aligned16(W)) ? 1 : 0);
+                       (ldw % 4 == 0 && aligned16(W)) ? 1 : 0, amax);
     return check_launch("weight_planes");
+}
+BTVAE_API int btvae_weight_planes(const float* W, int ldw, int N, int K, void* planes, int which, void* stream) {
+    return weight_planes_impl(W, ldw, N, K, planes, which, nullptr, stream);
+}
+// Two-piece mode: *amax = the absolute maximum of W (device scalar, final before the call, e.g. from btvae_absmax).  The
+// same buffer size; a product reads these planes only when it is also given that maximum (btvae_gemm_operand_maxima).
+BTVAE_API int btvae_weight_planes_f16(const float* W, int ldw, int N, int K, void* planes, int which, const float* amax, void* stream) {
+    BTVAE_REQUIRE(amax, "weight_planes_f16: null maximum");
+    return weight_planes_impl(W, ldw, N, K, planes, which, amax, stream);
+}
+
+// |x|-maximum of n floats folded into *out, which must hold zero or a maximum to extend.
+BTVAE_API int btvae_absmax(const float* x, long long n, float* out, void* stream) {
+    BTVAE_REQUIRE(x && out && n > 0, "absmax: bad arguments");
+    const unsigned blocks = (unsigned)std::min<long long>((n / 4 + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, out);
+    return check_launch("absmax");
+}
+
+// Absolute maxima (device scalars) of the A and B operand tensors of the NEXT product launched from the calling thread;
+// that launch consumes them.  In precision mode 3 a Linear-layer product that has both runs with two fp16 pieces per
+// value; one without, or any product in another mode, ignores them.  Each maximum must cover every element the product
+// reads of that operand (a larger value only costs precision; a smaller one overflows fp16).
+BTVAE_API int btvae_gemm_operand_maxima(const float* amax_a, const float* amax_b) {
+    t_amax_a = amax_a; t_amax_b = amax_b;
+    return 0;
 }
 
 // The same for `count` matrices (host arrays of length count, matrices contiguous with row pitch K[i]) in one launch
 // per 16 of them: the weights of a whole network at the start of a pass.
-BTVAE_API int btvae_weight_planes_multi(const float* const* W, const int* N, const int* K, void* const* planes, const int* which,
-                                        int count, void* stream) {
+static int weight_planes_multi_impl(const float* const* W, const int* N, const int* K, void* const* planes, const int* which,
+                                    const float* const* amax, int count, void* stream) {
     BTVAE_REQUIRE(W && N && K && planes && which && count > 0, "weight_planes_multi: bad arguments");
     for (int base = 0; base < count; base += PLANES_BATCH) {
         PlanesBatch b{};
@@ -511,11 +596,28 @@ BTVAE_API int btvae_weight_planes_multi(const float* const* W, const int* N, con
             BTVAE_REQUIRE(N[j] > 0 && K[j] > 0 && which[j] >= 1 && which[j] <= 3, "weight_planes_multi: entry %d: bad shape or image selection", j);
             b.W[i] = W[j]; b.planes[i] = (unsigned short*)planes[j]; b.ldw[i] = K[j]; b.R[i] = N[j]; b.C[i] = K[j]; b.which[i] = which[j];
             b.vec[i] = (K[j] % 4 == 0 && aligned16(W[j])) ? 1 : 0;
+            if (amax) { BTVAE_REQUIRE(amax[j], "weight_planes_multi: entry %d: null maximum", j); b.amax[i] = amax[j]; }
             most = std::max(most, (size_t)(((which[j] & 1) ? planes_f_elems(N[j], K[j]) : 0) + ((which[j] & 2) ? planes_d_elems(N[j], K[j]) : 0)) / 24);
         }
         hipLaunchKernelGGL(weight_planes_multi_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, b);
     }
     return check_launch("weight_planes_multi");
+}
+BTVAE_API int btvae_weight_planes_multi(const float* const* W, const int* N, const int* K, void* const* planes, const int* which,
+                                        int count, void* stream) {
+    return weight_planes_multi_impl(W, N, K, planes, which, nullptr, count, stream);
+}
+// Two-piece mode: amax[i] receives the absolute maximum of matrix i (computed here) and its planes are fp16 pieces.
+BTVAE_API int btvae_weight_planes_f16_multi(const float* const* W, const int* N, const int* K, void* const* planes, const int* which,
+                                            float* const* amax, int count, void* stream) {
+    BTVAE_REQUIRE(W && N && K && amax && count > 0, "weight_planes_f16_multi: bad arguments");
+    for (int i = 0; i < count; ++i) {
+        BTVAE_REQUIRE(W[i] && amax[i] && N[i] > 0 && K[i] > 0, "weight_planes_f16_multi: entry %d: bad arguments", i);
+        BTVAE_REQUIRE(hipMemsetAsync(amax[i], 0, sizeof(float), (hipStream_t)stream) == hipSuccess, "weight_planes_f16_multi: memset failed");
+        const int rc = btvae_absmax(W[i], (long long)N[i] * K[i], amax[i], stream);
+        if (rc) return rc;
+    }
+    return weight_planes_multi_impl(W, N, K, planes, which, amax, count, stream);
 }
 
 namespace {
@@ -567,7 +669,7 @@ BTVAE_API int btvae_linear_head_fwd(const float* X, int ldx, const float* W, con
     ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     // narrow heads (N <= 64) in the split mode: 128x64 tile instead of a mostly padded 128x128 one
     const bool vec_in = (ldx % 4 == 0) && (K % 4 == 0) && aligned16(X) && aligned16(W);
-    if (g_precision.load(std::memory_order_relaxed) == 2 && N <= NBN && vec_in && M > 0 && K > 0) {
+    if (g_precision.load(std::memory_order_relaxed) >= 2 && N <= NBN && vec_in && M > 0 && K > 0) {
         BTVAE_REQUIRE(X && W && Out, "linear_head_fwd: null operand");
         BTVAE_REQUIRE(ldx >= K, "linear_head_fwd: ldx %d < K %d", ldx, K);
         a.a_vec = a.b_vec = 1;

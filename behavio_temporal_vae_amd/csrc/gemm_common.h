@@ -40,6 +40,8 @@ struct GemmArgs {
     // split kernel only: B pre-split into bf16 planes stored tile by tile (null: split B in the kernel); bp_tiles =
     // 16-k tiles per tile of output columns
     const unsigned short* Bp; int bp_tiles;
+    // two-piece fp16 mode: absolute maxima of the operand tensors (device scalars), from which the kernel takes its scales
+    const float* amax_a; const float* amax_b;
     int a_vec, b_vec;
     int c_vec;                  // outputs / add-ins allow 16-byte row accesses: epilogue staged through LDS
     int tiles_m, tiles_n;

@@ -12,6 +12,14 @@
 // (s_off), one 16-byte read per plane and MFMA operand.  m/n-contiguous operands keep their orientation: a plane is
 // [16 k][128 m] bf16 (320-byte row pitch), stored with 8-byte writes straight from the loaded rows, and the MFMA operand
 // is gathered by the transposing LDS read (ds_read_b64_tr_b16, two per plane and operand).  48-60 KiB per workgroup.
+//
+// Two-piece variant (NPL = 2, precision mode 3): an operand value scaled by a power of two s is the sum p + q of two fp16
+// values (11 significant bits each, round to nearest) up to 2^-23 of its magnitude, and a*b ~ pp + pq + qp: three
+// v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones, the dropped qq term and the representation error are
+// ~2^-22 of |a*b|.  fp16 has five exponent bits, so each operand TENSOR is scaled to put its largest magnitude just below
+// 2^15 (the kernel derives s from the tensor's absolute maximum, which its producer left in device memory); elements more
+// than 2^17 below that maximum lose relative -- not absolute -- precision.  The accumulators are multiplied by 1/s_A and
+// 1/s_B (exact) before the epilogue.
 #pragma once
 #include "gemm_common.h"
 
@@ -48,6 +56,26 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& H, unsigned
     L = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
 }
 
+// power-of-two scale that puts a tensor whose absolute maximum is `amax` just below 2^15 (amax = 1.m * 2^(E-127) < 2^(E-126))
+__device__ __forceinline__ float scale_for(float amax) {
+    const int E = (int)((__float_as_uint(amax) >> 23) & 0xFFu);
+    if (E == 0 || E == 255) return 1.f;                    // zero / denormal / non-finite maximum: leave the values as they are
+    const int b = min(max(268 - E, 1), 254);
+    return __uint_as_float((unsigned)b << 23);
+}
+
+// (x0, x1) -> packed fp16 pairs of the two pieces of x*scale (x0 in the low half)
+__device__ __forceinline__ void split2h(float x0, float x1, float scale, unsigned& P, unsigned& Q) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const float y0 = x0 * scale, y1 = x1 * scale;
+    const _Float16 p0 = (_Float16)y0, p1 = (_Float16)y1;
+    const _Float16 q0 = (_Float16)(y0 - (float)p0), q1 = (_Float16)(y1 - (float)p1);
+    h2 pv, qv;
+    pv.x = p0; pv.y = p1; qv.x = q0; qv.y = q1;
+    P = __builtin_bit_cast(unsigned, pv);
+    Q = __builtin_bit_cast(unsigned, qv);
+}
+
 struct SStage { float v[8]; };           // 8 staged fp32 values per thread and operand
 struct PStage { unsigned v[12]; };       // pre-split B operand: 8 staged bf16 values of each plane per thread
 
@@ -81,6 +109,36 @@ __device__ __forceinline__ void s_g2r(const float* __restrict__ P, int ld, int r
             if (FULL) a = *reinterpret_cast<const float4*>(P + (size_t)gk * ld + min(gm, nrows - 4));
             else if (gk < kend && gm + 3 < nrows) a = *reinterpret_cast<const float4*>(P + (size_t)gk * ld + gm);
             sput4(st, j, a);         // v[4j + i] = element (k = 2kp + j, m = 4mq + i)
+        }
+    }
+}
+
+// the same with two fp16 pieces of the value times `scale` (planes at S, S + plane)
+template <int LAY>
+__device__ __forceinline__ void s_r2s2(__bf16* S, int tid, const SStage& st, float scale) {
+    const float* v = st.v;
+    if (LAY == LAY_K) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = tid + 256 * q;
+            const int row = f >> 2, kq = f & 3;
+            unsigned P0, Q0, P1, Q1;
+            split2h(v[4 * q], v[4 * q + 1], scale, P0, Q0);
+            split2h(v[4 * q + 2], v[4 * q + 3], scale, P1, Q1);
+            __bf16* dst = S + s_off(row, kq >> 1) + ((kq & 1) << 2);
+            *reinterpret_cast<uint2*>(dst) = make_uint2(P0, P1);
+            *reinterpret_cast<uint2*>(dst + SPLANE) = make_uint2(Q0, Q1);
+        }
+    } else {
+        const int mq = tid & 31, kp = tid >> 5;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned P0, Q0, P1, Q1;
+            split2h(v[4 * j], v[4 * j + 1], scale, P0, Q0);
+            split2h(v[4 * j + 2], v[4 * j + 3], scale, P1, Q1);
+            __bf16* dst = S + (kp * 2 + j) * MPITCH + (mq << 2);
+            *reinterpret_cast<uint2*>(dst) = make_uint2(P0, P1);
+            *reinterpret_cast<uint2*>(dst + MPLANE) = make_uint2(Q0, Q1);
         }
     }
 }
@@ -123,21 +181,22 @@ __device__ __forceinline__ void s_r2s(__bf16* S, int tid, const SStage& st) {
 // zero padded, the k tiles of one column tile consecutive.  A thread's share of a plane is the 16 bytes at 8*tid:
 // the loads are fully coalesced, need no bounds (every tile is whole) and go to LDS as they are -- no split arithmetic
 // for this operand.
+template <int NPL = 3>
 __device__ __forceinline__ void p_g2r(const GemmArgs& p, int n0, int k0, int tid, PStage& st) {
-    const unsigned short* src = p.Bp + (size_t)((n0 >> 7) * p.bp_tiles + (k0 >> 4)) * (3 * SPLANE) + (tid << 3);
+    const unsigned short* src = p.Bp + (size_t)((n0 >> 7) * p.bp_tiles + (k0 >> 4)) * (NPL * SPLANE) + (tid << 3);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < NPL; ++pl) {
         const uint4 q = *reinterpret_cast<const uint4*>(src + pl * SPLANE);
         st.v[4 * pl] = q.x; st.v[4 * pl + 1] = q.y; st.v[4 * pl + 2] = q.z; st.v[4 * pl + 3] = q.w;
     }
 }
 
-template <int LAY>
+template <int LAY, int NPL = 3>
 __device__ __forceinline__ void p_r2s(__bf16* S, int tid, const PStage& st) {
     constexpr int PL = LAY == LAY_K ? SPLANE : MPLANE;
     __bf16* dst = LAY == LAY_K ? S + (tid << 3) : S + (tid >> 4) * MPITCH + ((tid & 15) << 3);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
         *reinterpret_cast<uint4*>(dst + pl * PL) = make_uint4(st.v[4 * pl], st.v[4 * pl + 1], st.v[4 * pl + 2], st.v[4 * pl + 3]);
 }
 
@@ -182,13 +241,20 @@ __device__ __forceinline__ int s_frag_off(int blk, int lane) {
 template <bool PRE> struct BStageOf { typedef SStage type; };
 template <> struct BStageOf<true> { typedef PStage type; };
 
-// BPRE: the B operand comes pre-split (p.Bp) instead of as fp32 (p.B).
-template <int AL, int BL, int EPI, bool BPRE = false>
+// BPRE: the B operand comes pre-split (p.Bp) instead of as fp32 (p.B).  NPL: pieces per operand value (3 bf16, or 2 fp16
+// of the scaled value: p.amax_a / p.amax_b point at the operand tensors' absolute maxima).
+template <int AL, int BL, int EPI, bool BPRE = false, int NPL = 3>
 __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const GemmArgs p) {
     typedef typename BStageOf<BPRE>::type BStage;
+    typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
     constexpr int PD = BTVAE_SPLIT_PD;
     constexpr int PLA = plane_elems<AL>(), PLB = plane_elems<BL>();
-    __shared__ __attribute__((aligned(16))) __bf16 smem[2][3 * PLA + 3 * PLB];
+    constexpr int EPI_BF16 = (64 * EPL + 6 * 128) * 2;                 // the staged epilogue's LDS image, in 2-byte units
+    constexpr int BUF = NPL * PLA + NPL * PLB;
+    constexpr int LDS_ELEMS = 2 * BUF > EPI_BF16 ? 2 * BUF : EPI_BF16;
+    __shared__ __attribute__((aligned(16))) __bf16 smem_raw[LDS_ELEMS];
+    float sc_a = 1.f, sc_b = 1.f;
+    if (NPL == 2) { sc_a = scale_for(*p.amax_a); sc_b = scale_for(*p.amax_b); }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
 
@@ -210,13 +276,18 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
 
     // k-tile j of this workgroup into a register set (no-op past the last tile; full tiles need no predicates)
     auto fetch_b = [&](int k0, bool full, BStage& b) {
-        if constexpr (BPRE) p_g2r(p, n0, k0, tid, b);
+        if constexpr (BPRE) p_g2r<NPL>(p, n0, k0, tid, b);
         else if (full) s_g2r<BL, true>(p.B, p.ldb, n0, p.N, k0, kend, tid, b);
         else s_g2r<BL, false>(p.B, p.ldb, n0, p.N, k0, kend, tid, b);
     };
     auto publish_b = [&](__bf16* S, const BStage& b) {
-        if constexpr (BPRE) p_r2s<BL>(S, tid, b);
+        if constexpr (BPRE) p_r2s<BL, NPL>(S, tid, b);
+        else if constexpr (NPL == 2) s_r2s2<BL>(S, tid, b, sc_b);
         else s_r2s<BL>(S, tid, b);
+    };
+    auto publish_a = [&](__bf16* S, const SStage& a) {
+        if constexpr (NPL == 2) s_r2s2<AL>(S, tid, a, sc_a);
+        else s_r2s<AL>(S, tid, a);
     };
     auto fetch = [&](int j, SStage& a, BStage& b) {
         if (j >= nk) return;
@@ -235,8 +306,8 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
     BStage sb[PD];
     if (nk > 0) {
         fetch(0, sa[0], sb[0]);
-        s_r2s<AL>(smem[0], tid, sa[0]);
-        publish_b(smem[0] + 3 * PLA, sb[0]);
+        publish_a((smem_raw), sa[0]);
+        publish_b((smem_raw) + NPL * PLA, sb[0]);
     }
 #pragma unroll
     for (int j = 1; j <= PD; ++j) fetch(j, sa[j % PD], sb[j % PD]);
@@ -248,43 +319,58 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
     for (int i = 0; i < 2; ++i) { oa[i] = s_frag_off<AL>(wr * 64 + i * 32, lane); ob[i] = s_frag_off<BL>(wc * 64 + i * 32, lane); }
 
     auto tile_mma = [&](const __bf16* As, const __bf16* Bs) {
-        sbf16x8 a[3][2], b[3][2];
+        sbf16x8 a[NPL][2], b[NPL][2];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 a[pl][i] = s_frag<AL>(As + pl * PLA, oa[i]);
                 b[pl][i] = s_frag<BL>(Bs + pl * PLB, ob[i]);
             }
+        if constexpr (NPL == 2) {
+            // pq, qp, pp with the A operand stationary over consecutive instructions
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, a[1][i]), __builtin_bit_cast(sf16x8, b[0][j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int pb = 1; pb >= 0; --pb)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, a[0][i]), __builtin_bit_cast(sf16x8, b[pb][j]), acc[i][j], 0, 0, 0);
+            }
+        } else {
 #if BTVAE_SPLIT_ORDER == 1
-        // operand-stationary order: the A operand stays the same over consecutive matrix instructions (6, 4, 2 of them),
-        // small terms first within what that allows
+            // operand-stationary order: the A operand stays the same over consecutive matrix instructions (6, 4, 2 of them),
+            // small terms first within what that allows
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 2; ++i) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NPL - 1][i], b[0][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int pb = 1; pb >= 0; --pb)
+                for (int pb = 1; pb >= 0; --pb)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[pb][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[pb][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int pb = 2; pb >= 0; --pb)
+                for (int pb = NPL - 1; pb >= 0; --pb)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[pb][j], acc[i][j], 0, 0, 0);
-        }
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[pb][j], acc[i][j], 0, 0, 0);
+            }
 #else
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {      // small terms first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
-            }
+                for (int j = 0; j < 2; ++j) {      // small terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NPL - 1][i], b[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[NPL - 1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+                }
 #endif
+        }
     };
 
     // Iteration t: multiply tile t from LDS, publish tile t+1 from its register set, refill that set with tile
@@ -298,15 +384,15 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
         for (int u = 0; u < PD; ++u) {
             const int t = t0 + u;
             const int cur = t & 1;
-            tile_mma(smem[cur], smem[cur] + 3 * PLA);
-            s_r2s<AL>(smem[cur ^ 1], tid, sa[(u + 1) % PD]);
-            publish_b(smem[cur ^ 1] + 3 * PLA, sb[(u + 1) % PD]);
+            tile_mma((smem_raw + cur * BUF), (smem_raw + cur * BUF) + NPL * PLA);
+            publish_a((smem_raw + (cur ^ 1) * BUF), sa[(u + 1) % PD]);
+            publish_b((smem_raw + (cur ^ 1) * BUF) + NPL * PLA, sb[(u + 1) % PD]);
             const int k0 = kbeg + (t + 1 + PD) * SBK;
             s_g2r<AL, true>(p.A, p.lda, m0, p.M, k0, kend, tid, sa[(u + 1) % PD]);
             fetch_b(k0, true, sb[(u + 1) % PD]);
-            __builtin_amdgcn_sched_group_barrier(0x100, (AL == LAY_K ? 6 : 12) + (BL == LAY_K ? 6 : 12), 0);   // fragment reads
+            __builtin_amdgcn_sched_group_barrier(0x100, ((AL == LAY_K ? 2 : 4) + (BL == LAY_K ? 2 : 4)) * NPL, 0);   // fragment reads
 #pragma unroll
-            for (int k = 0; k < 24; ++k) {
+            for (int k = 0; k < (NPL == 2 ? 12 : 24); ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, BPRE ? BTVAE_SPLIT_VPM_PRE : BTVAE_SPLIT_VPM, 0);   // a few vector instructions
                 if (k & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // an LDS store
@@ -321,11 +407,11 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
             const int t = t0 + u;
             if (t < nk) {
                 const int cur = t & 1;
-                tile_mma(smem[cur], smem[cur] + 3 * PLA);
+                tile_mma((smem_raw + cur * BUF), (smem_raw + cur * BUF) + NPL * PLA);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < nk) {
-                    s_r2s<AL>(smem[cur ^ 1], tid, sa[(u + 1) % PD]);
-                    publish_b(smem[cur ^ 1] + 3 * PLA, sb[(u + 1) % PD]);
+                    publish_a((smem_raw + (cur ^ 1) * BUF), sa[(u + 1) % PD]);
+                    publish_b((smem_raw + (cur ^ 1) * BUF) + NPL * PLA, sb[(u + 1) % PD]);
                 }
                 fetch(t + 1 + PD, sa[(u + 1) % PD], sb[(u + 1) % PD]);
                 __syncthreads();
@@ -333,7 +419,16 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
         }
     }
 
-    gemm_epilogue<EPI>(p, acc, reinterpret_cast<float*>(&smem[0][0]), m0, n0, tile_m, zz);
+    if (NPL == 2) {
+        const float ia = 1.f / sc_a, ib = 1.f / sc_b;       // powers of two: exact, applied one after the other to stay in range
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] * ia) * ib;
+    }
+    gemm_epilogue<EPI>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, tile_m, zz);
 }
 
 }  // namespace btvae_gemm

@@ -190,15 +190,75 @@ PRESPLIT_WEIGHTS = not os.environ.get('BTVAE_NO_PRESPLIT')   # split mode: weigh
 PLANES_FWD, PLANES_DX = 1, 2
 
 
+def _split_mode() -> int:
+    """0 outside the split modes, else the number of pieces per operand value a Linear product may use (3 or 2)."""
+    return {2: 3, 3: 2}.get(nv.lib().btvae_get_gemm_precision(), 0)
+
+
+class _MaxSlots:
+    """Device scalars for the absolute maxima of GEMM operand tensors (two-piece mode), handed out from zero-filled
+    chunks; a slot lives as long as something references its view."""
+
+    CHUNK = 64
+
+    def __init__(self):
+        self.chunk, self.used = None, 0
+
+    def take(self, dev) -> torch.Tensor:
+        if self.chunk is None or self.used == self.CHUNK or self.chunk.device != dev:
+            self.chunk, self.used = torch.zeros(self.CHUNK, device=dev), 0
+        self.used += 1
+        return self.chunk[self.used - 1:self.used]
+
+
+MAX_SLOTS = _MaxSlots()
+
+
+def _amax(t: Optional[torch.Tensor], cache: bool = True) -> Optional[torch.Tensor]:
+    """Device scalar holding max |t| (two-piece mode; None otherwise).  Computed once per tensor object and content
+    version: a tensor the engine wrote with its own kernels is written once, one that torch ops modify in place changes
+    its version.  ``cache=False`` for tensors updated through raw pointers (parameters under the fused optimiser)."""
+    if t is None or _split_mode() != 2:
+        return None
+    hit = getattr(t, "_btvae_amax", None) if cache else None
+    if hit is not None and hit[1] == t._version:
+        return hit[0]
+    slot = MAX_SLOTS.take(t.device)
+    nv.call("btvae_absmax", P(t), t.numel(), P(slot))
+    if cache:
+        t._btvae_amax = (slot, t._version)
+    return slot
+
+
+def _operand_maxima(a: Optional[torch.Tensor], b: Optional[torch.Tensor]):
+    """Hand the next product its operands' maxima (both or nothing)."""
+    if a is not None and b is not None:
+        nv.lib().btvae_gemm_operand_maxima(P(a), P(b))
+
+
+def _planes_amax(planes: Optional[torch.Tensor], W: torch.Tensor) -> Optional[torch.Tensor]:
+    """Maximum that goes with a weight operand: the one its fp16 planes were scaled with, else computed from ``W`` now."""
+    if _split_mode() != 2:
+        return None
+    if planes is not None:
+        return planes._btvae_amax
+    return _amax(W, cache=False)
+
+
 def _weight_planes(W: torch.Tensor, which: int) -> Optional[torch.Tensor]:
     """bf16 planes of a weight matrix for the ``*_pw`` products (``btvae_weight_planes``; ``which``: the forward image,
     the dX image or both), or None outside the split mode.  They are a copy of ``W`` as it is now: made per forward
     pass, used by that pass and its backward."""
-    if not PRESPLIT_WEIGHTS or nv.lib().btvae_get_gemm_precision() != 2:
+    mode = _split_mode()
+    if not PRESPLIT_WEIGHTS or not mode:
         return None
     N, K = W.shape
     planes = torch.empty(nv.lib().btvae_weight_planes_elems(N, K), dtype=torch.int16, device=W.device)
-    nv.call("btvae_weight_planes", P(W), K, N, K, P(planes), which)
+    if mode == 2:
+        planes._btvae_amax = _amax(W, cache=False)
+        nv.call("btvae_weight_planes_f16", P(W), K, N, K, P(planes), which, P(planes._btvae_amax))
+    else:
+        nv.call("btvae_weight_planes", P(W), K, N, K, P(planes), which)
     return planes
 
 
@@ -206,7 +266,8 @@ def _plan_planes(plan: "NetPlan", backward: bool) -> Dict[torch.nn.Linear, torch
     """bf16 planes of every Linear weight of a network in one launch (``btvae_weight_planes_multi``) at the start of a
     pass: hidden Linears get the forward image (+ the dX image when a backward follows), head output Linears the dX
     image only (their forward kernel reads the fp32 weight).  Empty outside the split mode."""
-    if not PRESPLIT_WEIGHTS or nv.lib().btvae_get_gemm_precision() != 2:
+    mode = _split_mode()
+    if not PRESPLIT_WEIGHTS or not mode:
         return {}
     items = [(u.lin, PLANES_FWD | (PLANES_DX if backward else 0)) for u in plan.trunk]
     for units in plan.heads.values():
@@ -222,6 +283,15 @@ def _plan_planes(plan: "NetPlan", backward: bool) -> Dict[torch.nn.Linear, torch
         off += n
     cnt = len(items)
     PtrArr, IntArr = nv.c_void_p * cnt, nv.ctypes.c_int * cnt
+    if mode == 2:
+        maxima = torch.empty(cnt, device=buf.device)
+        for i, (lin, _) in enumerate(items):
+            out[lin]._btvae_amax = maxima[i:i + 1]
+        nv.call("btvae_weight_planes_f16_multi",
+                PtrArr(*[lin.weight.data_ptr() for lin, _ in items]), IntArr(*[lin.out_features for lin, _ in items]),
+                IntArr(*[lin.in_features for lin, _ in items]), PtrArr(*[out[lin].data_ptr() for lin, _ in items]),
+                IntArr(*[w for _, w in items]), PtrArr(*[maxima[i:i + 1].data_ptr() for i in range(cnt)]), cnt)
+        return out
     nv.call("btvae_weight_planes_multi",
             PtrArr(*[lin.weight.data_ptr() for lin, _ in items]), IntArr(*[lin.out_features for lin, _ in items]),
             IntArr(*[lin.in_features for lin, _ in items]), PtrArr(*[out[lin].data_ptr() for lin, _ in items]),
@@ -277,6 +347,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         tiles = (M + 127) // 128
         y = torch.empty(M, N, device=dev)
         part = WS.get("bnpart", tiles * 2 * N, dev)
+        _operand_maxima(_amax(x), _planes_amax(wp, W))
         nv.call("btvae_linear_relu_stats_fwd_pw", P(x), K, P(W), P(wp), P(b), P(y), P(part), M, K, N)
         mean, invstd = torch.empty(N, device=dev), torch.empty(N, device=dev)
         track = u.bn.track_running_stats and u.bn.running_mean is not None
@@ -311,6 +382,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
     elif u.bn is None and train:
         # unit built without BatchNorm: y = relu(x W^T + b) is what the backward needs; dropout / residual on top
         y = torch.empty(M, N, device=dev)
+        _operand_maxima(_amax(x), _planes_amax(wp, W))
         nv.call("btvae_linear_relu_affine_fwd_pw", P(x), K, P(W), P(wp), P(b), None, None, None, P(y), M, K, N)
         keep, ks = None, 1.0
         if u.dropout_p > 0.0:
@@ -328,6 +400,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         if u.bn is not None:
             scale, shift = torch.empty(N, device=dev), torch.empty(N, device=dev)
             nv.call("btvae_bn_fold_eval", P(u.bn.weight), P(u.bn.bias), P(u.bn.running_mean), P(u.bn.running_var), float(u.bn.eps), P(scale), P(shift), N)
+        _operand_maxima(_amax(x), _planes_amax(wp, W))
         nv.call("btvae_linear_relu_affine_fwd_pw", P(x), K, P(W), P(wp), P(b), P(scale), P(shift), P(x) if u.residual else None, P(out), M, K, N)
     return out
 
@@ -413,6 +486,7 @@ def _wgrad(lin: torch.nn.Linear, dy: torch.Tensor, x: torch.Tensor, x_scale, x_s
     M, N = dy.shape
     K = x.shape[1]
     ws = WS.get("wgrad", WGRAD_WS_FLOATS, dy.device)
+    _operand_maxima(_amax(dy), _amax(x))
     if x_scale is None:
         nv.call("btvae_linear_wgrad", P(dy), P(x), K, P(_grad_view(lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
     elif products is not None and BWD_SUMS_FROM_CONSUMERS:
@@ -449,6 +523,7 @@ def _dgrad_with_producer_backward(pr: BwdProducts, dy: torch.Tensor, W: torch.Te
     tiles = (M + 127) // 128
     dpre = torch.empty(M, Np, device=dev)
     part = WS.get("bnbwd_part", tiles * Np, dev)
+    _operand_maxima(_amax(dy), _planes_amax(planes, W))
     nv.call("btvae_linear_dgrad_bnbwd_pw", P(dy), P(W), P(planes), P(r), P(sv_p.y), P(sv_p.mean), P(sv_p.invstd), P(u_p.bn.weight), P(sums),
             int(max(sv_p.total_rows, M)), P(dpre), P(part), M, N, Np)
     db_cur = torch.empty(Np, device=dev) if sv_p.x_scale is not None else None
@@ -528,9 +603,11 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
             and src.out_products is None and K % 4 == 0):
         tiles = (M + 127) // 128
         part = torch.empty(tiles, 2, K, device=dev)
+        _operand_maxima(_amax(dpre), _planes_amax(sv.w_planes, u.lin.weight))
         nv.call("btvae_linear_dgrad_gstats_pw", P(dpre), P(u.lin.weight), P(sv.w_planes), P(r), P(src.y), P(src.mean), P(src.invstd), P(dx), P(part), M, N, K)
         src.g_partials = (part, tiles)
     else:
+        _operand_maxima(_amax(dpre), _planes_amax(sv.w_planes, u.lin.weight))
         nv.call("btvae_linear_dgrad_pw", P(dpre), P(u.lin.weight), P(sv.w_planes), P(r), P(dx), K, M, N, K)
     return dx
 
@@ -557,6 +634,7 @@ def net_backward(plan: NetPlan, tape: NetTape, draw: Dict[str, torch.Tensor], ne
             g = _dgrad_with_producer_backward(x_pr, d, last.lin.weight, None, accumulate, tape.head_planes.get(name))
         else:
             g = torch.empty(M, K, device=dev)
+            _operand_maxima(_amax(d), _planes_amax(tape.head_planes.get(name), last.lin.weight))
             nv.call("btvae_linear_dgrad_pw", P(d), P(last.lin.weight), P(tape.head_planes.get(name)), None, P(g), K, M, N, K)
         svs = tape.heads[name]
         for i in range(len(units) - 2, -1, -1):

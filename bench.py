@@ -50,10 +50,12 @@ SPLIT_TERMS = 6                  # bf16 MFMAs issued per fp32 product in the spl
 DOMINANT_KERNEL_HBM_BYTES = {"fp32": 2 * 324658 * 1024 + 304764 * 1024, "fp32_split": 2 * 505912 * 1024 + 258478 * 1024}
 
 
-KERNEL_NAME = {"fp32_split": "gemm_split_mfma", "fp32": "gemm_f32_mfma", "bf16": "gemm_bf16_mfma"}
+KERNEL_NAME = {"fp32_split": "gemm_split_mfma", "fp32_split2": "gemm_split_mfma", "fp32": "gemm_f32_mfma", "bf16": "gemm_bf16_mfma"}
 PRECISION_NOTE = {
     "fp32_split": "Linear products: fp32 operands as exact 3-way bf16 splits, 6 bf16 MFMAs per product with fp32 accumulation; "
                   "error against fp64 at or below the fp32 MFMA instruction's (tools/gemm_accuracy.py)",
+    "fp32_split2": "Linear products: fp32 operands as two fp16 pieces of the per-tensor-scaled value, 3 fp16 MFMAs per product with fp32 "
+                   "accumulation (products without tracked operand maxima: the 3-way bf16 split)",
     "fp32": "Linear products on the fp32 MFMA instruction",
     "bf16": "Linear products on bf16-rounded operands",
 }
@@ -177,6 +179,8 @@ def cpu_scoring_baseline(K=1000, N=32):
 def _peak(precision):
     if precision == "fp32_split":
         return PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS, "fp32-equivalent FLOP/s: bf16 dense peak 2500 / 6 bf16 MFMAs per fp32 product"
+    if precision == "fp32_split2":
+        return PEAK_BF16_MFMA_TFLOPS / 3, "fp32-equivalent FLOP/s: fp16 dense peak 2500 / 3 fp16 MFMAs per fp32 product"
     return (PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS), "dense matrix peak of the operand type"
 
 
@@ -556,8 +560,10 @@ def main():
                 "ms_per_step": tb / steps * 1e3, "steps": steps, "last_loss": float(lb["loss"].item())}
 
     main_precision = model.gemm_precision
-    native_opt = bf16_opt = None
+    native_opt = bf16_opt = split2_opt = None
     if args.option_steps > 0:
+        split2_opt = timed_option("fp32_split2", args.option_steps, "Linear products on two per-tensor-scaled fp16 pieces per value, "
+                                  "3 fp16 MFMAs per product where the engine tracks the operands' maxima, else as the headline")
         native_opt = timed_option("fp32", args.option_steps, "Linear products on the fp32 MFMA instruction, v_mfma_f32_32x32x2_f32")
         bf16_opt = timed_option("bf16", args.option_steps, "bf16 GEMM operands, fp32 accumulate and fp32 everywhere else")
 
@@ -599,7 +605,7 @@ def main():
                        "gemm_precision": main_precision, "step_replayed_from_hip_graph": graphed, "global_batch": world * B,
                        "per_gpu_batch": B, "num_mc_samples": S, "input_dim": D, "cond_dim": C, "latent_dim": 48, "hidden": 1000,
                        "vocab": 100, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": f"{KERNEL_NAME[main_precision]}<k-contig,k-contig,relu+stats{',pre-split weight' if main_precision == 'fp32_split' else ''}> M={S * B} N=K=1000 (decoder hidden Linear forward)",
+            "roofline": {"bound": "mfma", "kernel": f"{KERNEL_NAME[main_precision]}<k-contig,k-contig,relu+stats{',pre-split weight' if main_precision.startswith('fp32_split') else ''}> M={S * B} N=K=1000 (decoder hidden Linear forward)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": peak_note,
                          "fp32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                          "flops_per_launch": dom_fl, "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
@@ -622,6 +628,8 @@ def main():
             out["fp32_mfma_option"] = native_opt
         if bf16_opt is not None:
             out["bf16_option"] = bf16_opt
+        if split2_opt is not None:
+            out["fp32_split2_option"] = split2_opt
         for key, leg in (("imputation", imputation), ("wide_conditioning", wide), ("e2e", e2e)):
             if leg is not None:
                 out[key] = leg

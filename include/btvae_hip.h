@@ -35,7 +35,11 @@ int btvae_prof_dominant(int kind, double* ms, double* flops_per_launch, long lon
  * unless a model is configured otherwise).  1 = operands of the Linear-layer products
  * (btvae_linear_*_fwd, _dgrad, _wgrad) rounded to bf16 on the way into LDS, fp32 accumulation; the covariance products
  * stay fp32.  2 = every product fp32-accurate on the bf16 matrix pipe: operands split exactly into three bf16 pieces,
- * six bf16 MFMAs per product (error against fp64 at or below mode 0's).  Process-wide. */
+ * six bf16 MFMAs per product (error against fp64 at or below mode 0's).  3 = as 2, except that a Linear-layer product
+ * given the absolute maxima of its two operand tensors (btvae_gemm_operand_maxima) runs on two fp16 pieces per value
+ * of the tensor scaled by a power of two that puts its maximum just below 2^15: three fp16 MFMAs per product; the
+ * representation error of an element is ~2^-22 of its own magnitude down to 2^-18 of the tensor's maximum and ~2^-40
+ * of that maximum below it.  Process-wide. */
 int btvae_set_gemm_precision(int mode);
 int btvae_get_gemm_precision(void);
 
@@ -52,6 +56,21 @@ int btvae_weight_planes(const float* W, int ldw, int N, int K, void* planes, int
 /* The same for `count` contiguous matrices W[i][N[i]][K[i]] (host arrays of length count) in one launch per 16 entries. */
 int btvae_weight_planes_multi(const float* const* W, const int* N, const int* K, void* const* planes, const int* which,
                               int count, void* stream);
+
+/* Mode 3 (no counterpart in the reference: torch.nn.Linear multiplies fp32 values, src/submodels.py:15-17).
+ * btvae_absmax folds max|x| over n floats into the device scalar *out, which must hold zero or a maximum to extend.
+ * btvae_gemm_operand_maxima names the device scalars holding the maxima of the A operand (activations or gradients)
+ * and the B operand (weight, or activations for a weight gradient) of the NEXT product launched from the calling
+ * thread; that launch consumes them.  Each must be final on the product's stream and cover every element the product
+ * reads (a larger value costs precision, a smaller one overflows fp16).  btvae_weight_planes_f16 writes the planes of
+ * W as two fp16 pieces scaled by *amax (same buffer size and image selection as btvae_weight_planes); a *_pw product
+ * reads such planes only when it was also given the maxima, the weight's being the value the planes were made with.
+ * btvae_weight_planes_f16_multi computes each matrix's maximum into amax[i] (device scalars) and writes its planes. */
+int btvae_absmax(const float* x, long long n, float* out, void* stream);
+int btvae_gemm_operand_maxima(const float* amax_a, const float* amax_b);
+int btvae_weight_planes_f16(const float* W, int ldw, int N, int K, void* planes, int which, const float* amax, void* stream);
+int btvae_weight_planes_f16_multi(const float* const* W, const int* N, const int* K, void* const* planes, const int* which,
+                                  float* const* amax, int count, void* stream);
 
 /* ---- Linear layers on MFMA (src/submodels.py:15-17 Linear+ReLU, :20-21 BatchNorm1d, :28-35 NNBlock.forward) ---- */
 /* Y[M,N] = relu(X[M,K] W[N,K]^T + b); stat_partials[ceil(M/128)][2][N] = per-row-tile column (mean, M2). */

@@ -271,6 +271,137 @@ def test_presplit_weight_products(dev, gemm_mode, M, N, K):
         assert torch.equal(D0, D1) and torch.equal(g0, g1), "dgrad + BatchNorm backward sums"
 
 
+def absmax_of(t):
+    out = torch.zeros(1, device=t.device)
+    nv.call("btvae_absmax", P(t), t.numel(), P(out))
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 3, 1000, 4096 * 1000 + 3])
+def test_absmax(dev, n):
+    x = rnd(n + 1, seed=70).float().to(dev)
+    x[n // 2] = -7.5
+    for view in (x[:n], x[1:n + 1]):                 # 16-byte aligned and not
+        got = absmax_of(view.contiguous() if view.data_ptr() % 16 == 0 else view)
+        assert got.item() == view.abs().max().item()
+    keep = torch.full((1,), 100.0, device=dev)       # extends a maximum already in the slot
+    nv.call("btvae_absmax", P(x[:n]), n, P(keep))
+    assert keep.item() == 100.0
+    z = torch.zeros(8, device=dev)
+    assert absmax_of(z).item() == 0.0
+
+
+@pytest.fixture
+def two_piece():
+    nv.set_gemm_precision("fp32_split2")
+    yield
+    nv.lib().btvae_gemm_operand_maxima(None, None)
+    nv.set_gemm_precision("fp32")
+
+
+@pytest.mark.parametrize("M,N,K,sx,sg", [(300, 1000, 52, 1.0, 1.0), (257, 1000, 1000, 1.0, 1.0), (130, 72, 48, 30.0, 1e-6),
+                                         (1000, 100, 1000, 1e-3, 1e4), (640, 1000, 1000, 1.0, 1e-7)])
+def test_two_piece_products(dev, two_piece, M, N, K, sx, sg):
+    """Linear products on two scaled fp16 pieces per value (given the operands' maxima) against fp64, to the tolerances
+    of the fp32 products relative to the operands' scales; a product without maxima is bit-identical to the three-piece
+    mode.  Activations and gradients of very different magnitudes exercise the per-tensor scales."""
+    X, W, b = rnd(M, K, seed=41, scale=sx), rnd(N, K, seed=42, scale=0.2), rnd(N, seed=43, scale=0.1 * sx)
+    dY, R = rnd(M, N, seed=44, scale=sg), rnd(M, K, seed=45, scale=sg)
+    Xd, Wd, bd, dYd, Rd = (t.float().to(dev) for t in (X, W, b, dY, R))
+    c = {k: v.cpu().double() for k, v in dict(X=Xd, W=Wd, b=bd, dY=dYd, R=Rd).items()}
+    mx = {k: absmax_of(v) for k, v in dict(X=Xd, W=Wd, dY=dYd).items()}
+    L = nv.lib()
+    planes = torch.full((L.btvae_weight_planes_elems(N, K),), 0x7FC0, dtype=torch.int16, device=dev)
+    nv.call("btvae_weight_planes_f16", P(Wd), K, N, K, P(planes), 3, P(mx["W"]))
+    tiles = (M + 127) // 128
+    ref_y = torch.relu(c["X"] @ c["W"].t() + c["b"])
+    tol_f = 2e-6 * math.sqrt(K) * sx
+    Y3 = torch.empty(M, N, device=dev); p3 = torch.empty(tiles, 2, N, device=dev)
+    nv.set_gemm_precision("fp32_split")
+    nv.call("btvae_linear_relu_stats_fwd", P(Xd), K, P(Wd), P(bd), P(Y3), P(p3), M, K, N)
+    nv.set_gemm_precision("fp32_split2")
+    for pl in (None, planes):
+        Y = torch.empty(M, N, device=dev); part = torch.empty(tiles, 2, N, device=dev)
+        # without maxima: the three-piece kernel on the fp32 weight, whatever the planes hold
+        nv.call("btvae_linear_relu_stats_fwd_pw", P(Xd), K, P(Wd), P(pl), P(bd), P(Y), P(part), M, K, N)
+        assert torch.equal(Y, Y3) and torch.equal(part, p3)
+        L.btvae_gemm_operand_maxima(P(mx["X"]), P(mx["W"]))
+        nv.call("btvae_linear_relu_stats_fwd_pw", P(Xd), K, P(Wd), P(pl), P(bd), P(Y), P(part), M, K, N)
+        close(Y, ref_y, 2e-6, tol_f, "relu_stats")
+        if K >= 1000:
+            assert not torch.equal(Y, Y3), "the two-piece kernel did not run"
+        mean, invstd = torch.empty(N, device=dev), torch.empty(N, device=dev)
+        nv.call("btvae_bn_stats_finalize", P(part), tiles, M, N, P(mean), P(invstd), None, None, 0.1, 1e-5)
+        close(mean, Y.cpu().double().mean(0), 1e-5, 1e-6 * sx, "mean")
+        # the maxima were consumed: the next product is a three-piece one again
+        nv.call("btvae_linear_relu_stats_fwd_pw", P(Xd), K, P(Wd), P(pl), P(bd), P(Y), P(part), M, K, N)
+        assert torch.equal(Y, Y3)
+        sc, sh, Rn = rnd(N, seed=46).float().to(dev), rnd(N, seed=47).float().to(dev), rnd(M, N, seed=48).float().to(dev)
+        L.btvae_gemm_operand_maxima(P(mx["X"]), P(mx["W"]))
+        nv.call("btvae_linear_relu_affine_fwd_pw", P(Xd), K, P(Wd), P(pl), P(bd), P(sc), P(sh), P(Rn), P(Y), M, K, N)
+        close(Y, ref_y * sc.cpu().double() + sh.cpu().double() + Rn.cpu().double(), 1e-5, tol_f * 3 + 2e-5, "relu_affine")
+        D = torch.empty(M, K, device=dev)
+        ref_g = c["dY"] @ c["W"] + c["R"]
+        tol_d = 3e-6 * math.sqrt(N) * sg
+        L.btvae_gemm_operand_maxima(P(mx["dY"]), P(mx["W"]))
+        nv.call("btvae_linear_dgrad_pw", P(dYd), P(Wd), P(pl), P(Rd), P(D), K, M, N, K)
+        close(D, ref_g, 2e-6, tol_d, "dgrad")
+        if K % 4 == 0:
+            Yb = torch.relu(rnd(M, K, seed=49) + 0.2).float().to(dev)
+            mean, inv = Yb.mean(0), 1 / torch.sqrt(Yb.var(0, unbiased=False) + 1e-5)
+            gam = (1 + 0.3 * rnd(K, seed=50)).float().to(dev)
+            xhat = (Yb.cpu().double() - mean.cpu().double()) * inv.cpu().double()
+            g_part = torch.empty(tiles, 2, K, device=dev)
+            L.btvae_gemm_operand_maxima(P(mx["dY"]), P(mx["W"]))
+            nv.call("btvae_linear_dgrad_gstats_pw", P(dYd), P(Wd), P(pl), P(Rd), P(Yb), P(mean), P(inv), P(D), P(g_part), M, N, K)
+            close(D, ref_g, 2e-6, tol_d, "dgrad + sums: G")
+            sums, dgam, dbet = torch.empty(2, K, device=dev), torch.zeros(K, device=dev), torch.zeros(K, device=dev)
+            nv.call("btvae_bn_bwd_sums_from_partials", P(g_part), tiles, K, P(dgam), P(dbet), P(sums), 0)
+            s = math.sqrt(M) * (1 + float(inv.max())) * sg * math.sqrt(N) * 0.2
+            close(sums[0], ref_g.sum(0), 1e-5, 3e-6 * s, "sum G")
+            close(sums[1], (ref_g * xhat).sum(0), 1e-5, 9e-6 * s, "sum G*xhat")
+            s0, s1 = ref_g.sum(0), (ref_g * xhat).sum(0)
+            ref_dpre = torch.where(Yb.cpu() > 0, gam.cpu().double() * inv.cpu().double() * (ref_g - s0 / M - xhat * s1 / M), torch.zeros_like(ref_g))
+            sums_d = torch.stack([s0, s1]).float().to(dev)
+            cp = torch.empty(tiles, K, device=dev)
+            L.btvae_gemm_operand_maxima(P(mx["dY"]), P(mx["W"]))
+            nv.call("btvae_linear_dgrad_bnbwd_pw", P(dYd), P(Wd), P(pl), P(Rd), P(Yb), P(mean), P(inv), P(gam), P(sums_d), M, P(D), P(cp), M, N, K)
+            scale = float((gam * inv).abs().max()) * sg
+            close(D, ref_dpre, 1e-4, scale * (2e-6 * math.sqrt(N) + 1e-6 * math.sqrt(M)), "dgrad + BatchNorm backward")
+    ws = torch.empty(16 * N * K, device=dev)
+    dW = torch.full((N, K), 0.5, device=dev)
+    L.btvae_gemm_operand_maxima(P(mx["dY"]), P(mx["X"]))
+    nv.call("btvae_linear_wgrad", P(dYd), P(Xd), K, P(dW), P(ws), ws.numel(), M, N, K, 0)
+    close(dW, c["dY"].t() @ c["X"], 2e-6, 3e-6 * math.sqrt(M) * sx * sg, "wgrad")
+
+
+def test_two_piece_outlier_and_degenerate_scales(dev, two_piece):
+    """One element 2^20 above the rest of its tensor: the small elements keep an ABSOLUTE error of ~2^-40 of the maximum
+    (the result stays accurate relative to the outlier row's scale); all-zero operands and a maximum of 0 are fine."""
+    M, K, N = 256, 1000, 256
+    X, W = rnd(M, K, seed=80), rnd(N, K, seed=81, scale=0.2)
+    X[3, 5] = 2.0 ** 20
+    Xd, Wd, bd = X.float().to(dev), W.float().to(dev), torch.zeros(N, device=dev)
+    tiles = (M + 127) // 128
+    Y, part = torch.empty(M, N, device=dev), torch.empty(tiles, 2, N, device=dev)
+    L = nv.lib()
+    mx, mw = absmax_of(Xd), absmax_of(Wd)
+    L.btvae_gemm_operand_maxima(P(mx), P(mw))
+    nv.call("btvae_linear_relu_stats_fwd", P(Xd), K, P(Wd), P(bd), P(Y), P(part), M, K, N)
+    ref = torch.relu(Xd.cpu().double() @ Wd.cpu().double().t())
+    err = (Y.cpu().double() - ref).abs()
+    assert err[3].max() <= 2e-6 * 2.0 ** 20 * 0.2 * 4                # the outlier's row: relative to its own products
+    others = torch.ones(M, dtype=torch.bool); others[3] = False
+    # other rows: elements ~1 are ~2^-20 of the maximum, below the second piece's full-precision range (2^-18 of it):
+    # their error is the fp16 denormal spacing, 2^-39 of the maximum = 2^-19 absolute per element here
+    assert err[others].max() <= 2.0 ** -19 * 0.2 * 4 * math.sqrt(K)
+    Z = torch.zeros(M, K, device=dev)
+    mz = absmax_of(Z)
+    L.btvae_gemm_operand_maxima(P(mz), P(mw))
+    nv.call("btvae_linear_relu_stats_fwd", P(Z), K, P(Wd), P(bd), P(Y), P(part), M, K, N)
+    assert float(Y.abs().max()) == 0.0
+
+
 def test_weight_planes_batch(dev):
     """Planes of several matrices in one launch equal the one-matrix calls, image selection included."""
     import ctypes
