@@ -96,6 +96,7 @@ _RET = {
     "btvae_colsum_noalloc_max_floats": (c_longlong, []),
     "btvae_prof_enabled": (c_int, []),
     "btvae_gemm_operand_maxima": (c_int, [P, P]),
+    "btvae_output_maximum": (c_int, [P]),
 }
 EXPORTS = sorted(list(_SIGS) + list(_RET))
 PROF_KINDS = ["gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_mvn", "bn", "mvn_rows", "reduce", "optim"]
@@ -170,7 +171,11 @@ def call(name: str, *args):
     """Call a status-returning entry point on the current torch stream; raise on failure."""
     rc = getattr(lib(), name)(*args, stream_ptr())
     if rc != 0:
-        raise RuntimeError(f"{name}: {last_error()}")
+        msg = last_error()
+        # a request meant for the launch that did not happen must not reach a later one
+        lib().btvae_gemm_operand_maxima(None, None)
+        lib().btvae_output_maximum(None)
+        raise RuntimeError(f"{name}: {msg}")
 
 
 def f32(t, name="tensor"):

@@ -141,19 +141,21 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ R,
                                                            const unsigned char* __restrict__ keep, float keep_scale,
-                                                           float* __restrict__ Out, int M, int N, int rows_per_chunk) {
+                                                           float* __restrict__ Out, int M, int N, int rows_per_chunk,
+                                                           float* __restrict__ amax_out) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + lane) * VEC;
-    if (col >= N) return;
+    const bool ok = col < N;
+    float vmax = 0.f;
     float sc[VEC], sh[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        if (mean) {
+        if (mean && ok) {
             const float s = invstd[col + j] * gamma[col + j];
             sc[j] = s; sh[j] = beta[col + j] - mean[col + j] * s;
         } else { sc[j] = 1.f; sh[j] = 0.f; }      // no normalisation: dropout / residual only
     }
-    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = ok ? min(M, r0 + rows_per_chunk) : 0;
 #pragma unroll 4
     for (int r = r0 + w; r < r1; r += 4) {
         const size_t o = (size_t)r * N + col;
@@ -167,13 +169,16 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
             }
             if (R) { const float4 q = *reinterpret_cast<const float4*>(R + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
             *reinterpret_cast<float4*>(Out + o) = v;
+            vmax = amax4(vmax, v);
         } else {
             float v = Y[o] * sc[0] + sh[0];
             if (keep) v = keep[o] ? v * keep_scale : 0.f;
             if (R) v += R[o];
             Out[o] = v;
+            vmax = fmaxf(vmax, fabsf(v));
         }
     }
+    wave_amax_commit(vmax, amax_out);          // every lane is here (lanes past the last column hold 0)
 }
 
 // ---- backward pass 1: per column s1 = sum g, s2 = sum g * xhat ----
@@ -284,8 +289,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const unsigned char* __restrict__ keep, float keep_scale,
                                                            float* __restrict__ dPre,
                                                            float* __restrict__ db_partials, int M, int N, int rows_per_chunk,
-                                                           float invM) {          // 1 / rows the statistics were taken over
+                                                           float invM,            // 1 / rows the statistics were taken over
+                                                           float* __restrict__ amax_out) {
     __shared__ float red[4][64][VEC];
+    float vmax = 0.f;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + lane) * VEC;
     const bool ok = col < N;
@@ -320,6 +327,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 d.z = y.z > 0.f ? k0[2] * g.z - k1[2] - k2[2] * ((y.z - mu[2]) * is[2]) : 0.f;
                 d.w = y.w > 0.f ? k0[3] * g.w - k1[3] - k2[3] * ((y.w - mu[3]) * is[3]) : 0.f;
                 *reinterpret_cast<float4*>(dPre + o) = d;
+                vmax = amax4(vmax, d);
                 sb[0] += d.x; sb[1] += d.y; sb[2] += d.z; sb[3] += d.w;
             } else {
                 float g = G[o];
@@ -327,10 +335,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 if (keep) g = keep[o] ? g * keep_scale : 0.f;
                 const float d = y > 0.f ? k0[0] * g - k1[0] - k2[0] * ((y - mu[0]) * is[0]) : 0.f;
                 dPre[o] = d;
+                vmax = fmaxf(vmax, fabsf(d));
                 sb[0] += d;
             }
         }
     }
+    wave_amax_commit(vmax, amax_out);          // every lane is here (lanes past the last column hold 0)
 #pragma unroll
     for (int j = 0; j < VEC; ++j) red[w][lane][j] = sb[j];
     __syncthreads();
@@ -478,14 +488,15 @@ BTVAE_API int btvae_bn_fold_linear(const float* W, const float* b, const float* 
 BTVAE_API int btvae_bn_apply_fwd(const float* Y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                  const float* R, const unsigned char* keep, float keep_scale, float* Out, int M, int N,
                                  void* stream) {
+    float* amax_out = take_output_maximum();
     BTVAE_REQUIRE(Y && Out, "bn_apply_fwd: null pointer");
     BTVAE_REQUIRE(mean ? (invstd && gamma && beta) : (!invstd && !gamma && !beta), "bn_apply_fwd: pass all four BatchNorm vectors or none");
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
     ProfScope ps(PK_BN, (hipStream_t)stream, 0, 4.0 * M * N * (R ? 3 : 2) + (keep ? 1.0 * M * N : 0.0));
     if (vec4_ok(N, Y, R, Out, keep))
-        hipLaunchKernelGGL((bn_apply_fwd_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, keep, keep_scale, Out, M, N, rpc);
+        hipLaunchKernelGGL((bn_apply_fwd_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, keep, keep_scale, Out, M, N, rpc, amax_out);
     else
-        hipLaunchKernelGGL((bn_apply_fwd_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, keep, keep_scale, Out, M, N, rpc);
+        hipLaunchKernelGGL((bn_apply_fwd_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, keep, keep_scale, Out, M, N, rpc, amax_out);
     return check_launch("bn_apply_fwd");
 }
 
@@ -497,6 +508,7 @@ BTVAE_API int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mea
                                 const unsigned char* keep, float keep_scale,
                                 float* dgamma, float* dbeta, float* dbias, float* dbias_cur, float* dPre, float* scratch, int M, int N,
                                 int accumulate, void* stream) {
+    float* amax_out = take_output_maximum();
     BTVAE_REQUIRE(G && Y && mean && invstd && gamma && dgamma && dbeta && dbias && dPre && scratch, "bn_relu_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
@@ -510,8 +522,8 @@ BTVAE_API int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mea
     float* cur_dbeta = scratch + (size_t)3 * chunks * N;
     float* cur_dgamma = cur_dbeta + N;
     colsum_finalize(s, p2, chunks, 2, N, dbeta, dgamma, cur_dbeta, cur_dgamma, accumulate);
-    if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc, 1.f / (float)M);
-    else    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc, 1.f / (float)M);
+    if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc, 1.f / (float)M, amax_out);
+    else    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc, 1.f / (float)M, amax_out);
     colsum_finalize(s, p1, chunks, 1, N, dbias, (float*)nullptr, dbias_cur, (float*)nullptr, accumulate);
     return check_launch("bn_relu_bwd");
 }
@@ -558,6 +570,7 @@ BTVAE_API int btvae_bn_bwd_sums_from_products(const float* col_wp, const float* 
 BTVAE_API int btvae_bn_relu_bwd_apply(const float* G, const float* Y, const float* mean, const float* invstd, const float* gamma,
                                       const unsigned char* keep, float keep_scale, const float* sums, long long total_rows,
                                       float* dbias, float* dbias_cur, float* dPre, float* scratch, int M, int N, int accumulate, void* stream) {
+    float* amax_out = take_output_maximum();
     BTVAE_REQUIRE(G && Y && mean && invstd && gamma && sums && dbias && dPre && scratch, "bn_relu_bwd_apply: null pointer");
     BTVAE_REQUIRE(total_rows >= M, "bn_relu_bwd_apply: total_rows %lld < local rows %d", total_rows, M);
     hipStream_t s = (hipStream_t)stream;
@@ -565,9 +578,9 @@ BTVAE_API int btvae_bn_relu_bwd_apply(const float* G, const float* Y, const floa
     const float inv = 1.f / (float)total_rows;
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 3 + (keep ? 1.0 * M * N : 0.0));
     if (vec4_ok(N, G, Y, dPre, keep))
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, rpc, inv);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, rpc, inv, amax_out);
     else
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, rpc, inv);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, rpc, inv, amax_out);
     colsum_finalize(s, scratch, chunks, 1, N, dbias, (float*)nullptr, dbias_cur, (float*)nullptr, accumulate);
     return check_launch("bn_relu_bwd_apply");
 }
@@ -576,15 +589,16 @@ BTVAE_API int btvae_bn_relu_bwd_apply(const float* G, const float* Y, const floa
 // scratch: btvae_strip_chunks(M) * N floats.
 BTVAE_API int btvae_relu_bwd(const float* G, const float* Y, const unsigned char* keep, float keep_scale, float* dbias,
                              float* dbias_cur, float* dPre, float* scratch, int M, int N, int accumulate, void* stream) {
+    float* amax_out = take_output_maximum();
     BTVAE_REQUIRE(G && Y && dbias && dPre && scratch, "relu_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
     const float* none = nullptr;
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 3 + (keep ? 1.0 * M * N : 0.0));
     if (vec4_ok(N, G, Y, dPre, keep))
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc, 1.f);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc, 1.f, amax_out);
     else
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc, 1.f);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc, 1.f, amax_out);
     colsum_finalize(s, scratch, chunks, 1, N, dbias, (float*)nullptr, dbias_cur, (float*)nullptr, accumulate);
     return check_launch("relu_bwd");
 }

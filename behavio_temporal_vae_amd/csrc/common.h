@@ -33,6 +33,10 @@ struct ProfScope {
     ~ProfScope() { prof_end(kind, s); }
 };
 
+// Device scalar that the next producer launch from this thread folds max|output| into (btvae_output_maximum); the call
+// returns it and clears the request.
+float* take_output_maximum();
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error("%s: launch failed: %s", what, hipGetErrorString(e));
@@ -69,6 +73,16 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+// fold a lane-private non-negative maximum into *out (null: nothing): one integer atomic per wave at most -- non-negative
+// floats order like their bit patterns -- and none when the value already there is at least as large
+__device__ __forceinline__ void wave_amax_commit(float m, float* out) {
+    if (!out) return;
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f && m > *out) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
+__device__ __forceinline__ float amax4(float m, const float4 v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

@@ -60,6 +60,9 @@ void prof_end(int kind, hipStream_t s) {
     g_open = -1;
 }
 
+static thread_local float* t_out_max = nullptr;
+float* take_output_maximum() { float* p = t_out_max; t_out_max = nullptr; return p; }
+
 int noalloc_scratch_setup(int device);     // bn.hip: device address of the static scratch array on the current device
 
 }  // namespace btvae
@@ -89,6 +92,13 @@ BTVAE_API int btvae_init(int device) {
     if (prev != device) (void)hipSetDevice(prev);
     return rc;
 }
+
+// The next launch, from the calling thread, of a kernel that writes an operand of a later Linear product -- the forward
+// products with ReLU (btvae_linear_relu_stats_fwd*, btvae_linear_relu_affine_fwd*), btvae_bn_apply_fwd,
+// btvae_linear_dgrad_bnbwd*, btvae_bn_relu_bwd, btvae_bn_relu_bwd_apply, btvae_relu_bwd -- also folds the absolute
+// maximum of what it writes (Y / Out / dPre) into the device scalar *amax_out, which must hold zero or a maximum to
+// extend.  Any other entry point of the families above clears the request unused.
+BTVAE_API int btvae_output_maximum(float* amax_out) { t_out_max = amax_out; return 0; }
 
 // Turn event timing of kernel families on/off; turning it on clears earlier records.
 BTVAE_API int btvae_prof_enable(int on) {

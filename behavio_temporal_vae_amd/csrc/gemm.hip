@@ -417,21 +417,21 @@ inline long long planes_d_elems(int N, int K) { return (long long)((K + 127) / 1
 // order like their bits); *out must hold a non-negative value -- zero, or a maximum to extend -- beforehand.  NaNs are
 // skipped (fmaxf), infinities kept.
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
-    const size_t n4 = n >> 2;
+    const size_t n4 = n >> 2, step = (size_t)gridDim.x * 256;
     float m = 0.f;
-    const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    if (vec) {
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-            const float4 v = reinterpret_cast<const float4*>(x)[i];
-            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        for (; i + 3 * step < n4; i += 4 * step) {           // four loads in flight per thread
+            const float4 a = x4[i], b = x4[i + step], c = x4[i + 2 * step], d = x4[i + 3 * step];
+            m = amax4(amax4(amax4(amax4(m, a), b), c), d);
         }
-        for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+        for (; i < n4; i += step) m = amax4(m, x4[i]);
+        for (size_t j = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += step) m = fmaxf(m, fabsf(x[j]));
     } else {
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+        for (; i < n; i += step) m = fmaxf(m, fabsf(x[i]));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+    wave_amax_commit(m, out);
 }
 
 // which kernels exist with two fp16 pieces per operand value: the Linear layers' products
@@ -463,6 +463,8 @@ template <int AL, int BL, int EPI>
 int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduced_ok = false) {
     a.amax_a = t_amax_a; a.amax_b = t_amax_b;
     t_amax_a = t_amax_b = nullptr;
+    a.amax_out = btvae::take_output_maximum();
+    if (EPI != EPI_RELU_STATS && EPI != EPI_RELU_AFFINE && EPI != EPI_BNBWD) a.amax_out = nullptr;
     BTVAE_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "%s: empty problem M=%d N=%d K=%d", what, a.M, a.N, a.K);
     BTVAE_REQUIRE(a.A && a.B && a.C, "%s: null operand", what);
     BTVAE_REQUIRE(a.ldc >= a.N, "%s: ldc %d < N %d", what, a.ldc, a.N);
@@ -567,7 +569,7 @@ BTVAE_API int btvae_weight_planes_f16(const float* W, int ldw, int N, int K, voi
 // |x|-maximum of n floats folded into *out, which must hold zero or a maximum to extend.
 BTVAE_API int btvae_absmax(const float* x, long long n, float* out, void* stream) {
     BTVAE_REQUIRE(x && out && n > 0, "absmax: bad arguments");
-    const unsigned blocks = (unsigned)std::min<long long>((n / 4 + 255) / 256 + 1, 2048);
+    const unsigned blocks = (unsigned)std::min<long long>((n / 16 + 255) / 256 + 1, 1024);
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, out);
     return check_launch("absmax");
 }

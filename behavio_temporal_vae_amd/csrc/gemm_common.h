@@ -42,6 +42,7 @@ struct GemmArgs {
     const unsigned short* Bp; int bp_tiles;
     // two-piece fp16 mode: absolute maxima of the operand tensors (device scalars), from which the kernel takes its scales
     const float* amax_a; const float* amax_b;
+    float* amax_out;            // null, or where max |stored C| is folded in (EPI_RELU_STATS, EPI_RELU_AFFINE, EPI_BNBWD)
     int a_vec, b_vec;
     int c_vec;                  // outputs / add-ins allow 16-byte row accesses: epilogue staged through LDS
     int tiles_m, tiles_n;
@@ -108,6 +109,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x16 (
     float* Cz = p.C + (size_t)zz * p.slab_stride;
 
     float st_n[2], st_mean[2], st_m2[2];   // EPI_RELU_STATS: this lane's (count, mean, M2) per column block
+    float vmax = 0.f;                      // max |stored value| (EPI_RELU_STATS, EPI_RELU_AFFINE)
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         const int col = colg[cb];
@@ -135,6 +137,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x16 (
                     v = fmaxf(v + colv[cb][0], 0.f);
                     if (ok) {
                         Cz[(size_t)row * p.ldc + col] = v;
+                        vmax = fmaxf(vmax, v);
                         if (!have) { shiftK = v; have = true; }
                         const float d = v - shiftK;
                         s += d; q += d * d; cnt += 1.f;
@@ -144,6 +147,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x16 (
                     if (ok) {
                         if (p.R) v += p.R[(size_t)row * p.ldr + col];
                         Cz[(size_t)row * p.ldc + col] = v;
+                        vmax = fmaxf(vmax, fabsf(v));
                     }
                 } else if (EPI == EPI_HEAD) {
                     const float raw = v + colv[cb][0];
@@ -189,6 +193,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x16 (
         }
     }
 
+    if (EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE) wave_amax_commit(vmax, p.amax_out);
     if (EPI == EPI_RELU_STATS) {
         // red = [wr][3][128]
         if (lh == 0) {
@@ -233,6 +238,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, lh = lane >> 5;
     float* red = lds + 64 * EPL;
+    float vmax = 0.f;                              // max |stored value| (EPI_RELU_STATS, EPI_RELU_AFFINE, EPI_BNBWD)
     float bias[2], sc[2], sh[2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
@@ -351,10 +357,11 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             float4 v = ld4(lds + lr * EPL + c4);
             const size_t o = (size_t)row * p.ldc + col;
             if (USE_R && p.R) { const float4 q = rq[j]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-            if (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_RELU_AFFINE) {
+            if (EPI == EPI_PLAIN || EPI == EPI_BIAS) {
                 st4(Cz + o, v);
-            } else if (EPI == EPI_RELU_STATS) {
+            } else if (EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE) {
                 st4(Cz + o, v);
+                vmax = amax4(vmax, v);
             } else if (EPI == EPI_GSTATS) {
                 st4(Cz + o, v);
                 const float4 y = yq[j];
@@ -369,6 +376,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
                 d.z = y.z > 0.f ? bk0[2] * v.z - bk1[2] - bk2[2] * ((y.z - bmu[2]) * bis[2]) : 0.f;
                 d.w = y.w > 0.f ? bk0[3] * v.w - bk1[3] - bk2[3] * ((y.w - bmu[3]) * bis[3]) : 0.f;
                 st4(Cz + o, d);
+                vmax = amax4(vmax, d);
                 bsb[0] += d.x; bsb[1] += d.y; bsb[2] += d.z; bsb[3] += d.w;
             } else if (EPI == EPI_MUL) {
                 const float4 a = eq1[j], b = eq2[j];
@@ -415,6 +423,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
         __syncthreads();
     }
 
+    if (EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE || EPI == EPI_BNBWD) wave_amax_commit(vmax, p.amax_out);
     if (EPI == EPI_GSTATS) {
         float* cs = lds;                              // the image is free: the last half's barrier has passed
 #pragma unroll

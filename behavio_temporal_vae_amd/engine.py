@@ -199,10 +199,15 @@ class _MaxSlots:
     """Device scalars for the absolute maxima of GEMM operand tensors (two-piece mode), handed out from zero-filled
     chunks; a slot lives as long as something references its view."""
 
-    CHUNK = 64
+    CHUNK = 128
 
     def __init__(self):
         self.chunk, self.used = None, 0
+
+    def fresh(self):
+        """Start a new chunk with the next slot.  Every pass does: a pass captured into a HIP graph must zero its slots
+        inside the graph, or a replay would extend the previous replay's maxima instead of taking its own."""
+        self.chunk = None
 
     def take(self, dev) -> torch.Tensor:
         if self.chunk is None or self.used == self.CHUNK or self.chunk.device != dev:
@@ -228,6 +233,16 @@ def _amax(t: Optional[torch.Tensor], cache: bool = True) -> Optional[torch.Tenso
     if cache:
         t._btvae_amax = (slot, t._version)
     return slot
+
+
+def _track_output(t: torch.Tensor):
+    """Two-piece mode: have the producer kernel launched next leave max |t| in a fresh slot (``btvae_output_maximum``),
+    so that the products reading ``t`` need no pass of their own over it."""
+    if _split_mode() != 2:
+        return
+    slot = MAX_SLOTS.take(t.device)
+    nv.lib().btvae_output_maximum(P(slot))
+    t._btvae_amax = (slot, t._version)
 
 
 def _operand_maxima(a: Optional[torch.Tensor], b: Optional[torch.Tensor]):
@@ -348,6 +363,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         y = torch.empty(M, N, device=dev)
         part = WS.get("bnpart", tiles * 2 * N, dev)
         _operand_maxima(_amax(x), _planes_amax(wp, W))
+        _track_output(y)
         nv.call("btvae_linear_relu_stats_fwd_pw", P(x), K, P(W), P(wp), P(b), P(y), P(part), M, K, N)
         mean, invstd = torch.empty(N, device=dev), torch.empty(N, device=dev)
         track = u.bn.track_running_stats and u.bn.running_mean is not None
@@ -375,6 +391,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         if normed:
             return Normed(y, mean, invstd, u.bn.weight, u.bn.bias, out_pr)
         out = torch.empty(M, N, device=dev)
+        _track_output(out)
         nv.call("btvae_bn_apply_fwd", P(y), P(mean), P(invstd), P(u.bn.weight), P(u.bn.bias), P(x) if u.residual else None,
                 P(keep), ks, P(out), M, N)
         if saved is not None and keep is None:
@@ -383,12 +400,14 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         # unit built without BatchNorm: y = relu(x W^T + b) is what the backward needs; dropout / residual on top
         y = torch.empty(M, N, device=dev)
         _operand_maxima(_amax(x), _planes_amax(wp, W))
+        _track_output(y)
         nv.call("btvae_linear_relu_affine_fwd_pw", P(x), K, P(W), P(wp), P(b), None, None, None, P(y), M, K, N)
         keep, ks = None, 1.0
         if u.dropout_p > 0.0:
             keep, ks = DROPOUT.keep(M, N, u.dropout_p, dev), 1.0 / (1.0 - u.dropout_p)
         if keep is not None or u.residual:
             out = torch.empty(M, N, device=dev)
+            _track_output(out)
             nv.call("btvae_bn_apply_fwd", P(y), None, None, None, None, P(x) if u.residual else None, P(keep), ks, P(out), M, N)
         else:
             out = y
@@ -401,6 +420,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
             scale, shift = torch.empty(N, device=dev), torch.empty(N, device=dev)
             nv.call("btvae_bn_fold_eval", P(u.bn.weight), P(u.bn.bias), P(u.bn.running_mean), P(u.bn.running_var), float(u.bn.eps), P(scale), P(shift), N)
         _operand_maxima(_amax(x), _planes_amax(wp, W))
+        _track_output(out)
         nv.call("btvae_linear_relu_affine_fwd_pw", P(x), K, P(W), P(wp), P(b), P(scale), P(shift), P(x) if u.residual else None, P(out), M, K, N)
     return out
 
@@ -444,6 +464,7 @@ def net_forward(plan: NetPlan, x: torch.Tensor, train: bool, tape: Optional[NetT
     # if that is not residual, the first unit of every head for the trunk's last unit, the head's output Linear
     h = x
     nt = len(plan.trunk)
+    MAX_SLOTS.fresh()
     planes = _plan_planes(plan, tape is not None)
     for i, u in enumerate(plan.trunk):
         if i + 1 < nt:
@@ -524,6 +545,7 @@ def _dgrad_with_producer_backward(pr: BwdProducts, dy: torch.Tensor, W: torch.Te
     dpre = torch.empty(M, Np, device=dev)
     part = WS.get("bnbwd_part", tiles * Np, dev)
     _operand_maxima(_amax(dy), _planes_amax(planes, W))
+    _track_output(dpre)
     nv.call("btvae_linear_dgrad_bnbwd_pw", P(dy), P(W), P(planes), P(r), P(sv_p.y), P(sv_p.mean), P(sv_p.invstd), P(u_p.bn.weight), P(sums),
             int(max(sv_p.total_rows, M)), P(dpre), P(part), M, N, Np)
     db_cur = torch.empty(Np, device=dev) if sv_p.x_scale is not None else None
@@ -551,6 +573,7 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
     if fused_done:
         pass
     elif u.bn is None:
+        _track_output(dpre)
         nv.call("btvae_relu_bwd", P(g), P(sv.y), P(sv.keep), float(sv.keep_scale), P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
     elif pr is not None and pr.consumers > 0 and pr.filled == pr.consumers and sv.keep is None:
         # every reader of this unit's output was a folded Linear whose weight gradient has run: the column sums of
@@ -560,6 +583,7 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
                 P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)), P(sums), N, int(accumulate))
         if sv.total_rows > M:
             BN_SYNC.sum_(sums)
+        _track_output(dpre)
         nv.call("btvae_bn_relu_bwd_apply", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), None, 1.0,
                 P(sums), int(max(sv.total_rows, M)), P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
     elif sv.g_partials is not None:
@@ -569,6 +593,7 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
         nv.call("btvae_bn_bwd_sums_from_partials", P(part), tiles, N, P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)), P(sums), int(accumulate))
         if sv.total_rows > M:
             BN_SYNC.sum_(sums)
+        _track_output(dpre)
         nv.call("btvae_bn_relu_bwd_apply", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), None, 1.0,
                 P(sums), int(max(sv.total_rows, M)), P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
     elif sv.total_rows > M:
@@ -577,9 +602,11 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
         nv.call("btvae_bn_relu_bwd_sums", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(sv.keep), float(sv.keep_scale),
                 P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)), P(sums), P(scr), M, N, int(accumulate))
         BN_SYNC.sum_(sums)
+        _track_output(dpre)
         nv.call("btvae_bn_relu_bwd_apply", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
                 P(sums), int(sv.total_rows), P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
     else:
+        _track_output(dpre)
         nv.call("btvae_bn_relu_bwd", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
                 P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)),
                 P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))

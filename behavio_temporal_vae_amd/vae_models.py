@@ -31,7 +31,7 @@ except Exception:  # pragma: no cover
 
 # Linear products run as fp32 operands split into three bf16 pieces on the bf16 matrix pipe unless a model asks
 # otherwise: measured error against fp64 is at or below the fp32 MFMA kernel's, at 1.35x its speed.
-DEFAULT_GEMM_PRECISION = os.environ.get("BTVAE_GEMM_PRECISION", "fp32_split")
+DEFAULT_GEMM_PRECISION = os.environ.get("BTVAE_GEMM_PRECISION", "fp32_split2")
 
 
 class ScalarLogWriter:
@@ -198,8 +198,9 @@ class VAE(torch.nn.Module):
         self._arena = None
         self._grad_arena = None
         self._dp_world = 1
-        # operand precision of the Linear products: "fp32_split" (default; fp32-accurate on the bf16 matrix pipe), "fp32"
-        # (the fp32 MFMA instruction) or "bf16"; an extra keyword of the model config, swallowed by the reference's
+        # operand precision of the Linear products: "fp32_split2" (default: two per-tensor-scaled fp16 pieces per value, 3
+        # matrix instructions per product, error against fp64 at the fp32 MFMA instruction's level), "fp32_split" (three bf16
+        # pieces: the fp32 values exactly, 6 matrix instructions), "fp32" (the fp32 MFMA instruction) or "bf16"; an extra keyword of the model config, swallowed by the reference's
         # constructors like any other unknown key
         self.gemm_precision = DEFAULT_GEMM_PRECISION
         self.set_gemm_precision(_.get("gemm_precision", DEFAULT_GEMM_PRECISION))

@@ -17,6 +17,7 @@ cores, rank 0, N=1 only).  ``--scaling strong`` keeps the global batch at ``--ba
 """
 import argparse
 import contextlib
+import gc
 import json
 import math
 import os
@@ -490,6 +491,11 @@ def main():
 
     for i in range(args.warmup):
         loss = step(i)
+    # A full (generation-2) collection of the interpreter's garbage collector walks every object torch's import left
+    # behind: ~70 ms of host time during which nothing is launched, 5 steps' worth.  What exists now is moved out of the
+    # collector's reach, as long-running training loops do; the steps' own garbage is still collected.
+    gc.collect()
+    gc.freeze()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -560,12 +566,15 @@ def main():
                 "ms_per_step": tb / steps * 1e3, "steps": steps, "last_loss": float(lb["loss"].item())}
 
     main_precision = model.gemm_precision
-    native_opt = bf16_opt = split2_opt = None
+    options = {}
     if args.option_steps > 0:
-        split2_opt = timed_option("fp32_split2", args.option_steps, "Linear products on two per-tensor-scaled fp16 pieces per value, "
-                                  "3 fp16 MFMAs per product where the engine tracks the operands' maxima, else as the headline")
-        native_opt = timed_option("fp32", args.option_steps, "Linear products on the fp32 MFMA instruction, v_mfma_f32_32x32x2_f32")
-        bf16_opt = timed_option("bf16", args.option_steps, "bf16 GEMM operands, fp32 accumulate and fp32 everywhere else")
+        notes = {"fp32_split2": ("fp32_split2_option", "Linear products on two per-tensor-scaled fp16 pieces per value, 3 fp16 MFMAs per product"),
+                 "fp32_split": ("fp32_split_option", "Linear products on three bf16 pieces per value (the fp32 values exactly), 6 bf16 MFMAs per product"),
+                 "fp32": ("fp32_mfma_option", "Linear products on the fp32 MFMA instruction, v_mfma_f32_32x32x2_f32"),
+                 "bf16": ("bf16_option", "bf16 GEMM operands, fp32 accumulate and fp32 everywhere else")}
+        for prec, (key, what) in notes.items():
+            if prec != main_precision:
+                options[key] = timed_option(prec, args.option_steps, what)
 
     scoring = imputation = e2e = wide = None
     del pool
@@ -624,12 +633,7 @@ def main():
         }
         if scoring is not None:
             out["secondary"] = scoring
-        if native_opt is not None:
-            out["fp32_mfma_option"] = native_opt
-        if bf16_opt is not None:
-            out["bf16_option"] = bf16_opt
-        if split2_opt is not None:
-            out["fp32_split2_option"] = split2_opt
+        out.update(options)
         for key, leg in (("imputation", imputation), ("wide_conditioning", wide), ("e2e", e2e)):
             if leg is not None:
                 out[key] = leg

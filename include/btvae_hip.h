@@ -65,8 +65,13 @@ int btvae_weight_planes_multi(const float* const* W, const int* N, const int* K,
  * reads (a larger value costs precision, a smaller one overflows fp16).  btvae_weight_planes_f16 writes the planes of
  * W as two fp16 pieces scaled by *amax (same buffer size and image selection as btvae_weight_planes); a *_pw product
  * reads such planes only when it was also given the maxima, the weight's being the value the planes were made with.
- * btvae_weight_planes_f16_multi computes each matrix's maximum into amax[i] (device scalars) and writes its planes. */
+ * btvae_weight_planes_f16_multi computes each matrix's maximum into amax[i] (device scalars) and writes its planes.
+ * btvae_output_maximum asks the next launch, from the calling thread, of a kernel that writes an operand of a later
+ * Linear product (btvae_linear_relu_stats_fwd*, btvae_linear_relu_affine_fwd*, btvae_bn_apply_fwd,
+ * btvae_linear_dgrad_bnbwd*, btvae_bn_relu_bwd, btvae_bn_relu_bwd_apply, btvae_relu_bwd) to fold max|Y / Out / dPre|
+ * into *amax_out as btvae_absmax would, without a pass of its own. */
 int btvae_absmax(const float* x, long long n, float* out, void* stream);
+int btvae_output_maximum(float* amax_out);
 int btvae_gemm_operand_maxima(const float* amax_a, const float* amax_b);
 int btvae_weight_planes_f16(const float* W, int ldw, int N, int K, void* planes, int which, const float* amax, void* stream);
 int btvae_weight_planes_f16_multi(const float* const* W, const int* N, const int* K, void* const* planes, const int* which,

@@ -402,6 +402,66 @@ def test_two_piece_outlier_and_degenerate_scales(dev, two_piece):
     assert float(Y.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 1000, 52), (130, 72, 48), (257, 33, 40)])
+def test_output_maximum_from_producers(dev, gemm_mode, M, N, K):
+    """btvae_output_maximum: the next producer launch leaves max |what it wrote| in the slot (exactly: a maximum involves
+    no rounding), extends a value already there, and the request does not outlive that launch."""
+    L = nv.lib()
+    X, W, b = rnd(M, K, seed=91).float().to(dev), rnd(N, K, seed=92, scale=0.2).float().to(dev), rnd(N, seed=93, scale=0.1).float().to(dev)
+    tiles = (M + 127) // 128
+    Y, part = torch.empty(M, N, device=dev), torch.empty(tiles, 2, N, device=dev)
+    slot = torch.zeros(1, device=dev)
+    L.btvae_output_maximum(P(slot))
+    nv.call("btvae_linear_relu_stats_fwd", P(X), K, P(W), P(b), P(Y), P(part), M, K, N)
+    assert slot.item() == Y.abs().max().item() > 0
+    slot.fill_(1e6)
+    L.btvae_output_maximum(P(slot))
+    nv.call("btvae_linear_relu_stats_fwd", P(X), K, P(W), P(b), P(Y), P(part), M, K, N)
+    assert slot.item() == 1e6
+    nv.call("btvae_linear_relu_stats_fwd", P(X), K, P(W), P(b), P(Y), P(part), M, K, N)      # no request pending
+    assert slot.item() == 1e6
+    sc, sh, R = rnd(N, seed=94).float().to(dev), rnd(N, seed=95).float().to(dev), rnd(M, N, seed=96).float().to(dev)
+    out = torch.empty(M, N, device=dev)
+    slot.zero_()
+    L.btvae_output_maximum(P(slot))
+    nv.call("btvae_linear_relu_affine_fwd", P(X), K, P(W), P(b), P(sc), P(sh), P(R), P(out), M, K, N)
+    assert slot.item() == out.abs().max().item()
+    mean, inv = Y.mean(0), 1 / torch.sqrt(Y.var(0, unbiased=False) + 1e-5)
+    gam, bet = (1 + 0.3 * rnd(N, seed=97)).float().to(dev), rnd(N, seed=98).float().to(dev)
+    slot.zero_()
+    L.btvae_output_maximum(P(slot))
+    nv.call("btvae_bn_apply_fwd", P(Y), P(mean), P(inv), P(gam), P(bet), P(R), None, 1.0, P(out), M, N)
+    assert slot.item() == out.abs().max().item()
+    G = rnd(M, N, seed=99).float().to(dev)
+    dpre = torch.empty(M, N, device=dev)
+    scr = torch.empty(L.btvae_bn_relu_bwd_scratch(M, N), device=dev)
+    dg, dbt, dbi = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    slot.zero_()
+    L.btvae_output_maximum(P(slot))
+    nv.call("btvae_bn_relu_bwd", P(G), P(Y), P(mean), P(inv), P(gam), None, 1.0, P(dg), P(dbt), P(dbi), None, P(dpre), P(scr), M, N, 0)
+    assert slot.item() == dpre.abs().max().item()
+    slot.zero_()
+    L.btvae_output_maximum(P(slot))
+    nv.call("btvae_relu_bwd", P(G), P(Y), None, 1.0, P(dbi), None, P(dpre), P(scr), M, N, 0)
+    assert slot.item() == dpre.abs().max().item()
+    if N % 4 == 0:
+        dY = rnd(M, K, seed=100).float().to(dev)          # dX product of a Linear [K out, N in]: G = dY Wt, Wt [K, N]
+        Wt = rnd(K, N, seed=101, scale=0.2).float().to(dev)
+        sums = rnd(2, N, seed=102).float().to(dev)
+        cp = torch.empty(tiles, N, device=dev)
+        slot.zero_()
+        L.btvae_output_maximum(P(slot))
+        nv.call("btvae_linear_dgrad_bnbwd", P(dY), P(Wt), None, P(Y), P(mean), P(inv), P(gam), P(sums), M, P(dpre), P(cp), M, K, N)
+        assert slot.item() == dpre.abs().max().item()
+    # a product that is no producer drops the request
+    L.btvae_output_maximum(P(slot))
+    D = torch.empty(M, K, device=dev)
+    nv.call("btvae_linear_dgrad", P(Y), P(W), None, P(D), K, M, N, K)
+    before = slot.item()
+    nv.call("btvae_linear_relu_stats_fwd", P(X), K, P(W), P(b), P(Y), P(part), M, K, N)
+    assert slot.item() == before
+
+
 def test_weight_planes_batch(dev):
     """Planes of several matrices in one launch equal the one-matrix calls, image selection included."""
     import ctypes

@@ -39,15 +39,41 @@ def main():
     dX = torch.empty(M, K, device=dev)
     dW = torch.empty(N, K, device=dev)
     ws = torch.empty(32 * 1024 * 1024, device=dev)
-    planes = torch.empty(nv.lib().btvae_weight_planes_elems(N, K), dtype=torch.int16, device=dev)
-    nv.call("btvae_weight_planes", P(W), K, N, K, P(planes), 3)
+    two = nv.get_gemm_precision() == "fp32_split2"
+    mx = {}
+
+    def amax(t):
+        if id(t) not in mx:
+            mx[id(t)] = torch.zeros(1, device=dev)
+            nv.call("btvae_absmax", P(t), t.numel(), P(mx[id(t)]))
+        return mx[id(t)]
+
+    def make_planes(Wm, n, k):
+        pl = torch.empty(nv.lib().btvae_weight_planes_elems(n, k), dtype=torch.int16, device=dev)
+        if two:
+            nv.call("btvae_weight_planes_f16", P(Wm), k, n, k, P(pl), 3, P(amax(Wm)))
+        else:
+            nv.call("btvae_weight_planes", P(Wm), k, n, k, P(pl), 3)
+        return pl
+
+    def mxd(fn, a, b):
+        """``fn`` preceded, in the two-piece mode, by the maxima of its A and B operand tensors."""
+        if not two:
+            return fn
+        ma, mb = amax(a), amax(b)
+
+        def run():
+            nv.lib().btvae_gemm_operand_maxima(P(ma), P(mb))
+            fn()
+        return run
+
+    planes = make_planes(W, N, K)
     # head-output shapes (reduction over V=100 outputs): epilogue- and HBM-heavy dX product fused with the producing
     # unit's BatchNorm backward, and the head forward
     V = 100
     Wh = torch.randn(V, K, device=dev, generator=g) * 0.03
     dV = torch.randn(M, V, device=dev, generator=g)
-    hp = torch.empty(nv.lib().btvae_weight_planes_elems(V, K), dtype=torch.int16, device=dev)
-    nv.call("btvae_weight_planes", P(Wh), K, V, K, P(hp), 3)
+    hp = make_planes(Wh, V, K)
     mean, inv, gam, sums = (torch.rand(K, device=dev, generator=g) + 0.5 for _ in range(4))
     sums2 = torch.randn(2, K, device=dev, generator=g)
     colpart = torch.empty((M + 127) // 128, K, device=dev)
@@ -65,8 +91,16 @@ def main():
         "dgrad": lambda: nv.call("btvae_linear_dgrad", P(Y), P(W), None, P(dX), K, M, N, K),
         "wgrad": lambda: nv.call("btvae_linear_wgrad", P(Y), P(X), K, P(dW), P(ws), ws.numel(), M, N, K, 0),
     }
+    Y.normal_(generator=g)         # the dX entries read Y as their A operand before any forward entry has written it
+    a_of = {"headout_bnbwd": (dV, Wh), "headout_plain": (dV, Wh), "headout_gstats": (dV, Wh), "gstats_big": (Y, W), "bnbwd_big": (Y, W),
+            "fwd_pw": (X, W), "dgrad_pw": (Y, W), "fwd": (X, W), "dgrad": (Y, W), "wgrad": (Y, X)}
     if N != K:
         ops = {k: v for k, v in ops.items() if k in ("fwd", "fwd_pw")}
+    if which != "all":             # run (and warm up with) the selected entry only: a forward entry would rewrite Y, whose
+        ops = {k: v for k, v in ops.items() if k == which}      # maximum the dX entries were given
+    elif two:
+        ops = {k: v for k, v in ops.items() if not k.startswith("fwd") and k != "head_fwd"}
+    ops = {k: (mxd(v, *a_of[k]) if k in a_of else v) for k, v in ops.items()}
     for _ in range(15):          # let the clock settle before anything is timed
         for fn in ops.values():
             fn()
