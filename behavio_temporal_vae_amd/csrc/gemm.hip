@@ -471,7 +471,6 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     BTVAE_REQUIRE(a.lda >= (AL == LAY_K ? a.K : a.M), "%s: lda %d too small", what, a.lda);
     BTVAE_REQUIRE(a.ldb >= (BL == LAY_K ? a.K : a.N), "%s: ldb %d too small", what, a.ldb);
     a.tiles_m = (a.M + BM - 1) / BM;
-    a.tiles_n = (a.N + BN - 1) / BN;
     // the vector path treats every 4-float chunk as all-or-nothing, so the contiguous extent must be a multiple of 4
     a.a_vec = (a.lda % 4 == 0) && aligned16(a.A) && ((AL == LAY_K ? a.K : a.M) % 4 == 0);
     a.b_vec = (a.ldb % 4 == 0) && aligned16(a.B) && ((BL == LAY_K ? a.K : a.N) % 4 == 0);
@@ -484,6 +483,10 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     const bool split = prec >= 2 && a.a_vec && a.b_vec;          // fp32-accurate: every product may use it
     const bool two = split && prec == 3 && has_twopiece<AL, BL, EPI>() && a.amax_a && a.amax_b;
     if (prec == 3 && !two) a.Bp = nullptr;                       // planes made in this mode hold fp16 pieces
+    // 128 x 256 block tile: the weight gradients, whose two operands are both split in the kernel (+5-10 %; the products
+    // with a pre-split weight gain nothing from it and short reductions lose to its longer epilogue)
+    const bool wide = two && AL == LAY_M && a.N > BN && a.K >= 256;
+    a.tiles_n = (a.N + (wide ? 2 * BN : BN) - 1) / (wide ? 2 * BN : BN);
     const int bk = bf16 ? HBK : split ? SBK : BK;
     a.kchunk = (((a.K + splits - 1) / splits) + bk - 1) / bk * bk;
     splits = (a.K + a.kchunk - 1) / a.kchunk;
@@ -499,6 +502,9 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
             }
         }
         if constexpr (has_twopiece<AL, BL, EPI>()) {
+            if constexpr (AL == LAY_M) {
+                if (!pre && wide) { pre = true; hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI, false, 2, 2>), grid, dim3(256), 0, s, a); }
+            }
             if (!pre && two) { pre = true; hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI, false, 2>), grid, dim3(256), 0, s, a); }
         }
         if (!pre) hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI>), grid, dim3(256), 0, s, a);

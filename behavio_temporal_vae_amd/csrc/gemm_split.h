@@ -183,7 +183,8 @@ __device__ __forceinline__ void s_r2s(__bf16* S, int tid, const SStage& st) {
 // for this operand.
 template <int NPL = 3>
 __device__ __forceinline__ void p_g2r(const GemmArgs& p, int n0, int k0, int tid, PStage& st) {
-    const unsigned short* src = p.Bp + (size_t)((n0 >> 7) * p.bp_tiles + (k0 >> 4)) * (NPL * SPLANE) + (tid << 3);
+    const int blk = min(n0 >> 7, (p.N - 1) >> 7);            // a column sub-tile past the matrix re-reads the last block
+    const unsigned short* src = p.Bp + (size_t)(blk * p.bp_tiles + (k0 >> 4)) * (NPL * SPLANE) + (tid << 3);
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) {
         const uint4 q = *reinterpret_cast<const uint4*>(src + pl * SPLANE);
@@ -224,6 +225,9 @@ __device__ __forceinline__ int s_frag_off(int blk, int lane) {
 #ifndef BTVAE_SPLIT_PD
 #define BTVAE_SPLIT_PD 2          // k-tiles in flight in registers ahead of the one being multiplied
 #endif
+#ifndef BTVAE_SPLIT_PD_WIDE
+#define BTVAE_SPLIT_PD_WIDE 2     // the same for the 128 x 256 block tile
+#endif
 #ifndef BTVAE_SPLIT_VPM
 #define BTVAE_SPLIT_VPM 5         // vector instructions of the split scheduled behind each MFMA
 #endif
@@ -237,20 +241,26 @@ __device__ __forceinline__ int s_frag_off(int blk, int lane) {
 #ifndef BTVAE_SPLIT_WG
 #define BTVAE_SPLIT_WG 2          // workgroups per CU the register budget is set for
 #endif
+#ifndef BTVAE_SPLIT_WG_TWO
+#define BTVAE_SPLIT_WG_TWO 2      // the same for the two-piece kernels on the 128 x 128 tile (36-40 KiB of LDS per workgroup)
+#endif
 
 template <bool PRE> struct BStageOf { typedef SStage type; };
 template <> struct BStageOf<true> { typedef PStage type; };
 
 // BPRE: the B operand comes pre-split (p.Bp) instead of as fp32 (p.B).  NPL: pieces per operand value (3 bf16, or 2 fp16
-// of the scaled value: p.amax_a / p.amax_b point at the operand tensors' absolute maxima).
-template <int AL, int BL, int EPI, bool BPRE = false, int NPL = 3>
-__global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const GemmArgs p) {
+// of the scaled value: p.amax_a / p.amax_b point at the operand tensors' absolute maxima).  NB: 128-column sub-tiles of
+// B per workgroup (block tile 128 x 128*NB, wave tile 64 x 64*NB): with 2, one staged-and-split A tile and one barrier feed
+// twice the matrix instructions (p.tiles_n counts the 128*NB-wide tiles).
+template <int AL, int BL, int EPI, bool BPRE = false, int NPL = 3, int NB = 1>
+__global__ __launch_bounds__(256, (NPL == 2 && NB == 1) ? BTVAE_SPLIT_WG_TWO : BTVAE_SPLIT_WG) void gemm_split_mfma(const GemmArgs p) {
     typedef typename BStageOf<BPRE>::type BStage;
     typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
-    constexpr int PD = BTVAE_SPLIT_PD;
+    constexpr int PD = NB == 2 ? BTVAE_SPLIT_PD_WIDE : BTVAE_SPLIT_PD;
     constexpr int PLA = plane_elems<AL>(), PLB = plane_elems<BL>();
     constexpr int EPI_BF16 = (64 * EPL + 6 * 128) * 2;                 // the staged epilogue's LDS image, in 2-byte units
-    constexpr int BUF = NPL * PLA + NPL * PLB;
+    constexpr int BUF = NPL * PLA + NB * NPL * PLB;
+    constexpr int BOFF = NPL * PLA, BSUB = NPL * PLB;               // first B sub-tile inside a buffer, elements per sub-tile
     constexpr int LDS_ELEMS = 2 * BUF > EPI_BF16 ? 2 * BUF : EPI_BF16;
     __shared__ __attribute__((aligned(16))) __bf16 smem_raw[LDS_ELEMS];
     float sc_a = 1.f, sc_b = 1.f;
@@ -261,35 +271,43 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
     int zz;
     const int bid = wg_tile(p, zz);
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = tile_m * BM, n0 = tile_n * (BN * NB);
     const int kbeg = zz * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int nk = kend > kbeg ? (kend - kbeg + SBK - 1) / SBK : 0;
 
-    f32x16 acc[2][2];
+    f32x16 acc[NB][2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int h = 0; h < NB; ++h)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
 
     // k-tile j of this workgroup into a register set (no-op past the last tile; full tiles need no predicates)
-    auto fetch_b = [&](int k0, bool full, BStage& b) {
-        if constexpr (BPRE) p_g2r<NPL>(p, n0, k0, tid, b);
-        else if (full) s_g2r<BL, true>(p.B, p.ldb, n0, p.N, k0, kend, tid, b);
-        else s_g2r<BL, false>(p.B, p.ldb, n0, p.N, k0, kend, tid, b);
+    auto fetch_b = [&](int k0, bool full, BStage (&b)[NB]) {
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
+            if constexpr (BPRE) p_g2r<NPL>(p, n0 + h * BN, k0, tid, b[h]);
+            else if (full) s_g2r<BL, true>(p.B, p.ldb, n0 + h * BN, p.N, k0, kend, tid, b[h]);
+            else s_g2r<BL, false>(p.B, p.ldb, n0 + h * BN, p.N, k0, kend, tid, b[h]);
+        }
     };
-    auto publish_b = [&](__bf16* S, const BStage& b) {
-        if constexpr (BPRE) p_r2s<BL, NPL>(S, tid, b);
-        else if constexpr (NPL == 2) s_r2s2<BL>(S, tid, b, sc_b);
-        else s_r2s<BL>(S, tid, b);
+    auto publish_b = [&](__bf16* S, const BStage (&b)[NB]) {
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
+            if constexpr (BPRE) p_r2s<BL, NPL>(S + h * BSUB, tid, b[h]);
+            else if constexpr (NPL == 2) s_r2s2<BL>(S + h * BSUB, tid, b[h], sc_b);
+            else s_r2s<BL>(S + h * BSUB, tid, b[h]);
+        }
     };
     auto publish_a = [&](__bf16* S, const SStage& a) {
         if constexpr (NPL == 2) s_r2s2<AL>(S, tid, a, sc_a);
         else s_r2s<AL>(S, tid, a);
     };
-    auto fetch = [&](int j, SStage& a, BStage& b) {
+    auto fetch = [&](int j, SStage& a, BStage (&b)[NB]) {
         if (j >= nk) return;
         const int k0 = kbeg + j * SBK;
         if (k0 + SBK <= kend) {
@@ -303,11 +321,11 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
 
     // Register sets: tile j (j >= 1) travels in set j % PD.  Tile 0 goes straight to LDS through set 0.
     SStage sa[PD];
-    BStage sb[PD];
+    BStage sb[PD][NB];
     if (nk > 0) {
         fetch(0, sa[0], sb[0]);
         publish_a((smem_raw), sa[0]);
-        publish_b((smem_raw) + NPL * PLA, sb[0]);
+        publish_b((smem_raw) + BOFF, sb[0]);
     }
 #pragma unroll
     for (int j = 1; j <= PD; ++j) fetch(j, sa[j % PD], sb[j % PD]);
@@ -318,58 +336,65 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
 #pragma unroll
     for (int i = 0; i < 2; ++i) { oa[i] = s_frag_off<AL>(wr * 64 + i * 32, lane); ob[i] = s_frag_off<BL>(wc * 64 + i * 32, lane); }
 
-    auto tile_mma = [&](const __bf16* As, const __bf16* Bs) {
-        sbf16x8 a[NPL][2], b[NPL][2];
+    auto tile_mma = [&](const __bf16* As, const __bf16* Bs0) {
+        sbf16x8 a[NPL][2];
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[pl][i] = s_frag<AL>(As + pl * PLA, oa[i]);
-                b[pl][i] = s_frag<BL>(Bs + pl * PLB, ob[i]);
-            }
-        if constexpr (NPL == 2) {
-            // pq, qp, pp with the A operand stationary over consecutive instructions
+            for (int i = 0; i < 2; ++i) a[pl][i] = s_frag<AL>(As + pl * PLA, oa[i]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+        for (int h = 0; h < NB; ++h) {
+            const __bf16* Bs = Bs0 + h * BSUB;
+            f32x16 (&ac)[2][2] = acc[h];
+            sbf16x8 b[NPL][2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, a[1][i]), __builtin_bit_cast(sf16x8, b[0][j]), acc[i][j], 0, 0, 0);
+            for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-                for (int pb = 1; pb >= 0; --pb)
+                for (int i = 0; i < 2; ++i) b[pl][i] = s_frag<BL>(Bs + pl * PLB, ob[i]);
+            if constexpr (NPL == 2) {
+                // pq, qp, pp with the A operand stationary over consecutive instructions
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, a[0][i]), __builtin_bit_cast(sf16x8, b[pb][j]), acc[i][j], 0, 0, 0);
-            }
-        } else {
+                        ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, a[1][i]), __builtin_bit_cast(sf16x8, b[0][j]), ac[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int pb = 1; pb >= 0; --pb)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sf16x8, a[0][i]), __builtin_bit_cast(sf16x8, b[pb][j]), ac[i][j], 0, 0, 0);
+                }
+            } else {
 #if BTVAE_SPLIT_ORDER == 1
-            // operand-stationary order: the A operand stays the same over consecutive matrix instructions (6, 4, 2 of them),
-            // small terms first within what that allows
+                // operand-stationary order: the A operand stays the same over consecutive matrix instructions (6, 4, 2 of
+                // them), small terms first within what that allows
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < 2; ++i) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NPL - 1][i], b[0][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NPL - 1][i], b[0][j], ac[i][j], 0, 0, 0);
 #pragma unroll
-                for (int pb = 1; pb >= 0; --pb)
+                    for (int pb = 1; pb >= 0; --pb)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[pb][j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < 2; ++j) ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[pb][j], ac[i][j], 0, 0, 0);
 #pragma unroll
-                for (int pb = NPL - 1; pb >= 0; --pb)
+                    for (int pb = NPL - 1; pb >= 0; --pb)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[pb][j], acc[i][j], 0, 0, 0);
-            }
+                        for (int j = 0; j < 2; ++j) ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[pb][j], ac[i][j], 0, 0, 0);
+                }
 #else
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {      // small terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NPL - 1][i], b[0][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[NPL - 1][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
-                }
+                    for (int j = 0; j < 2; ++j) {      // small terms first
+                        ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NPL - 1][i], b[0][j], ac[i][j], 0, 0, 0);
+                        ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[NPL - 1][j], ac[i][j], 0, 0, 0);
+                        ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], ac[i][j], 0, 0, 0);
+                        ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], ac[i][j], 0, 0, 0);
+                        ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], ac[i][j], 0, 0, 0);
+                        ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], ac[i][j], 0, 0, 0);
+                    }
 #endif
+            }
         }
     };
 
@@ -384,15 +409,16 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
         for (int u = 0; u < PD; ++u) {
             const int t = t0 + u;
             const int cur = t & 1;
-            tile_mma((smem_raw + cur * BUF), (smem_raw + cur * BUF) + NPL * PLA);
+            tile_mma((smem_raw + cur * BUF), (smem_raw + cur * BUF) + BOFF);
             publish_a((smem_raw + (cur ^ 1) * BUF), sa[(u + 1) % PD]);
-            publish_b((smem_raw + (cur ^ 1) * BUF) + NPL * PLA, sb[(u + 1) % PD]);
+            publish_b((smem_raw + (cur ^ 1) * BUF) + BOFF, sb[(u + 1) % PD]);
             const int k0 = kbeg + (t + 1 + PD) * SBK;
             s_g2r<AL, true>(p.A, p.lda, m0, p.M, k0, kend, tid, sa[(u + 1) % PD]);
             fetch_b(k0, true, sb[(u + 1) % PD]);
-            __builtin_amdgcn_sched_group_barrier(0x100, ((AL == LAY_K ? 2 : 4) + (BL == LAY_K ? 2 : 4)) * NPL, 0);   // fragment reads
+            __builtin_amdgcn_sched_group_barrier(0x100, ((AL == LAY_K ? 2 : 4) + (BL == LAY_K ? 2 : 4)) * NPL, 0);   // fragment reads (A, first B sub-tile)
 #pragma unroll
-            for (int k = 0; k < (NPL == 2 ? 12 : 24); ++k) {
+            for (int k = 0; k < (NPL == 2 ? 12 : 24) * NB; ++k) {
+                if (NB == 2 && k == (NPL == 2 ? 6 : 12)) __builtin_amdgcn_sched_group_barrier(0x100, (BL == LAY_K ? 2 : 4) * NPL, 0);   // second sub-tile's
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, BPRE ? BTVAE_SPLIT_VPM_PRE : BTVAE_SPLIT_VPM, 0);   // a few vector instructions
                 if (k & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // an LDS store
@@ -407,11 +433,11 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
             const int t = t0 + u;
             if (t < nk) {
                 const int cur = t & 1;
-                tile_mma((smem_raw + cur * BUF), (smem_raw + cur * BUF) + NPL * PLA);
+                tile_mma((smem_raw + cur * BUF), (smem_raw + cur * BUF) + BOFF);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < nk) {
                     publish_a((smem_raw + (cur ^ 1) * BUF), sa[(u + 1) % PD]);
-                    publish_b((smem_raw + (cur ^ 1) * BUF) + NPL * PLA, sb[(u + 1) % PD]);
+                    publish_b((smem_raw + (cur ^ 1) * BUF) + BOFF, sb[(u + 1) % PD]);
                 }
                 fetch(t + 1 + PD, sa[(u + 1) % PD], sb[(u + 1) % PD]);
                 __syncthreads();
@@ -419,16 +445,23 @@ __global__ __launch_bounds__(256, BTVAE_SPLIT_WG) void gemm_split_mfma(const Gem
         }
     }
 
-    if (NPL == 2) {
-        const float ia = 1.f / sc_a, ib = 1.f / sc_b;       // powers of two: exact, applied one after the other to stay in range
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int h = 0; h < NB; ++h) {
+        if (h > 0) {
+            if (n0 + h * BN >= p.N) break;                  // uniform: the sub-tile lies past the last column
+            __syncthreads();                                // the previous sub-tile's epilogue is done with the LDS image
+        }
+        if (NPL == 2) {
+            const float ia = 1.f / sc_a, ib = 1.f / sc_b;   // powers of two: exact, applied one after the other to stay in range
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = (acc[i][j][r] * ia) * ib;
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[h][i][j][r] = (acc[h][i][j][r] * ia) * ib;
+        }
+        gemm_epilogue<EPI>(p, acc[h], reinterpret_cast<float*>(smem_raw), m0, n0 + h * BN, tile_m, zz);
     }
-    gemm_epilogue<EPI>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, tile_m, zz);
 }
 
 }  // namespace btvae_gemm
