@@ -242,7 +242,9 @@ __device__ __forceinline__ int s_frag_off(int blk, int lane) {
 #define BTVAE_SPLIT_WG 2          // workgroups per CU the register budget is set for
 #endif
 #ifndef BTVAE_SPLIT_WG_TWO
-#define BTVAE_SPLIT_WG_TWO 2      // the same for the two-piece kernels on the 128 x 128 tile (36-40 KiB of LDS per workgroup)
+#define BTVAE_SPLIT_WG_TWO 3      // the same for the two-piece forward kernels (128 x 128 tile, 36 KiB of LDS per workgroup): a third
+                                  // workgroup per CU covers the other two's store phases (-3.5 % on the family; the dX and
+                                  // weight-gradient kernels gain nothing from it)
 #endif
 
 template <bool PRE> struct BStageOf { typedef SStage type; };
@@ -253,7 +255,7 @@ template <> struct BStageOf<true> { typedef PStage type; };
 // B per workgroup (block tile 128 x 128*NB, wave tile 64 x 64*NB): with 2, one staged-and-split A tile and one barrier feed
 // twice the matrix instructions (p.tiles_n counts the 128*NB-wide tiles).
 template <int AL, int BL, int EPI, bool BPRE = false, int NPL = 3, int NB = 1>
-__global__ __launch_bounds__(256, (NPL == 2 && NB == 1) ? BTVAE_SPLIT_WG_TWO : BTVAE_SPLIT_WG) void gemm_split_mfma(const GemmArgs p) {
+__global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && BL == LAY_K) ? BTVAE_SPLIT_WG_TWO : BTVAE_SPLIT_WG) void gemm_split_mfma(const GemmArgs p) {
     typedef typename BStageOf<BPRE>::type BStage;
     typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
     constexpr int PD = NB == 2 ? BTVAE_SPLIT_PD_WIDE : BTVAE_SPLIT_PD;
