@@ -48,7 +48,8 @@ BREAKDOWN_STEPS = 3             # untimed steps with every launch event-timed, f
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X bf16 dense matrix peak (v_mfma_f32_32x32x16_bf16, 1024 FLOP/clk/SIMD)
 SPLIT_TERMS = 6                  # bf16 MFMAs issued per fp32 product in the split mode
 # HBM-side bytes of one launch of the dominant kernel (M=65536, N=K=1000) from PMC passes kept under profiles/
-DOMINANT_KERNEL_HBM_BYTES = {"fp32": 2 * 324658 * 1024 + 304764 * 1024, "fp32_split": 2 * 505912 * 1024 + 258478 * 1024}
+DOMINANT_KERNEL_HBM_BYTES = {"fp32": 2 * 324658 * 1024 + 304764 * 1024, "fp32_split": 2 * 505912 * 1024 + 258478 * 1024,
+                             "fp32_split2": 2 * 345092 * 1024 + 260049 * 1024}
 
 
 KERNEL_NAME = {"fp32_split": "gemm_split_mfma", "fp32_split2": "gemm_split_mfma", "fp32": "gemm_f32_mfma", "bf16": "gemm_bf16_mfma"}
@@ -621,7 +622,7 @@ def main():
                          "measured_in": ("5 eager steps right after the timed region (the timed steps are replayed from a HIP graph)" if graphed
                                          else "the timed region"),
                          "traffic": DOMINANT_KERNEL_HBM_BYTES.get(main_precision) if (S * B == 65536) else None,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this kernel at this shape, separate passes: profiles/r1_gemm_fwd_pmc.md (not collected live)",
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this kernel at this shape, separate passes: profiles/r2_gemm_two_piece_pmc.md (fp32_split2), profiles/r1_gemm_fwd_pmc.md (other modes); not collected live",
                          "algorithmic_bytes": 4.0 * (S * B * 1000 + 1000 * 1000 + S * B * 1000),
                          "fwd_family_tflops": fwd_fl / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else None,
                          "all_gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None,
