@@ -219,19 +219,17 @@ class _MaxSlots:
 MAX_SLOTS = _MaxSlots()
 
 
-def _amax(t: Optional[torch.Tensor], cache: bool = True) -> Optional[torch.Tensor]:
-    """Device scalar holding max |t| (two-piece mode; None otherwise).  Computed once per tensor object and content
-    version: a tensor the engine wrote with its own kernels is written once, one that torch ops modify in place changes
-    its version.  ``cache=False`` for tensors updated through raw pointers (parameters under the fused optimiser)."""
+def _amax(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """Device scalar holding max |t| (two-piece mode; None otherwise): the slot its producer kernel filled when the
+    engine made ``t`` itself (``_track_output``; such tensors are written once), else a pass over ``t`` now -- network
+    inputs, head gradients and weights may change between two uses without this module seeing it, so nothing is cached
+    for them."""
     if t is None or _split_mode() != 2:
         return None
-    hit = getattr(t, "_btvae_amax", None) if cache else None
-    if hit is not None and hit[1] == t._version:
-        return hit[0]
-    slot = MAX_SLOTS.take(t.device)
-    nv.call("btvae_absmax", P(t), t.numel(), P(slot))
-    if cache:
-        t._btvae_amax = (slot, t._version)
+    slot = getattr(t, "_btvae_amax", None)
+    if slot is None:
+        slot = MAX_SLOTS.take(t.device)
+        nv.call("btvae_absmax", P(t), t.numel(), P(slot))
     return slot
 
 
@@ -242,7 +240,7 @@ def _track_output(t: torch.Tensor):
         return
     slot = MAX_SLOTS.take(t.device)
     nv.lib().btvae_output_maximum(P(slot))
-    t._btvae_amax = (slot, t._version)
+    t._btvae_amax = slot
 
 
 def _operand_maxima(a: Optional[torch.Tensor], b: Optional[torch.Tensor]):
@@ -257,7 +255,7 @@ def _planes_amax(planes: Optional[torch.Tensor], W: torch.Tensor) -> Optional[to
         return None
     if planes is not None:
         return planes._btvae_amax
-    return _amax(W, cache=False)
+    return _amax(W)
 
 
 def _weight_planes(W: torch.Tensor, which: int) -> Optional[torch.Tensor]:
@@ -270,7 +268,7 @@ def _weight_planes(W: torch.Tensor, which: int) -> Optional[torch.Tensor]:
     N, K = W.shape
     planes = torch.empty(nv.lib().btvae_weight_planes_elems(N, K), dtype=torch.int16, device=W.device)
     if mode == 2:
-        planes._btvae_amax = _amax(W, cache=False)
+        planes._btvae_amax = _amax(W)
         nv.call("btvae_weight_planes_f16", P(W), K, N, K, P(planes), which, P(planes._btvae_amax))
     else:
         nv.call("btvae_weight_planes", P(W), K, N, K, P(planes), which)
