@@ -416,7 +416,7 @@ inline long long planes_d_elems(int N, int K) { return (long long)((K + 127) / 1
 // absolute maximum of n floats folded into *out with an integer atomic maximum on the bit pattern (non-negative floats
 // order like their bits); *out must hold a non-negative value -- zero, or a maximum to extend -- beforehand.  NaNs are
 // skipped (fmaxf), infinities kept.
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+__device__ __forceinline__ void absmax_body(const float* __restrict__ x, size_t n, float* __restrict__ out) {
     const size_t n4 = n >> 2, step = (size_t)gridDim.x * 256;
     float m = 0.f;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -433,6 +433,12 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     }
     wave_amax_commit(m, out);
 }
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) { absmax_body(x, n, out); }
+
+// several tensors in one launch: blockIdx.y selects the entry
+struct AbsmaxBatch { const float* x[16]; float* out[16]; size_t n[16]; };
+__global__ __launch_bounds__(256) void absmax_multi_kernel(const AbsmaxBatch b) { absmax_body(b.x[blockIdx.y], b.n[blockIdx.y], b.out[blockIdx.y]); }
 
 // which kernels exist with two fp16 pieces per operand value: the Linear layers' products
 template <int AL, int BL, int EPI> constexpr bool has_twopiece() {
@@ -619,12 +625,26 @@ BTVAE_API int btvae_weight_planes_multi(const float* const* W, const int* N, con
 BTVAE_API int btvae_weight_planes_f16_multi(const float* const* W, const int* N, const int* K, void* const* planes, const int* which,
                                             float* const* amax, int count, void* stream) {
     BTVAE_REQUIRE(W && N && K && amax && count > 0, "weight_planes_f16_multi: bad arguments");
-    for (int i = 0; i < count; ++i) {
-        BTVAE_REQUIRE(W[i] && amax[i] && N[i] > 0 && K[i] > 0, "weight_planes_f16_multi: entry %d: bad arguments", i);
-        BTVAE_REQUIRE(hipMemsetAsync(amax[i], 0, sizeof(float), (hipStream_t)stream) == hipSuccess, "weight_planes_f16_multi: memset failed");
-        const int rc = btvae_absmax(W[i], (long long)N[i] * K[i], amax[i], stream);
-        if (rc) return rc;
+    for (int base = 0; base < count; base += 16) {
+        AbsmaxBatch b{};
+        const int n = std::min(16, count - base);
+        size_t most = 0;
+        for (int i = 0; i < n; ++i) {
+            const int j = base + i;
+            BTVAE_REQUIRE(W[j] && amax[j] && N[j] > 0 && K[j] > 0, "weight_planes_f16_multi: entry %d: bad arguments", j);
+            b.x[i] = W[j]; b.out[i] = amax[j]; b.n[i] = (size_t)N[j] * K[j];
+            most = std::max(most, b.n[i]);
+            // slots that are neighbours in memory are cleared together
+            if (i == 0 || amax[j] != amax[j - 1] + 1) {
+                int run = 1;
+                while (i + run < n && amax[j + run] == amax[j] + run) ++run;
+                BTVAE_REQUIRE(hipMemsetAsync(amax[j], 0, sizeof(float) * run, (hipStream_t)stream) == hipSuccess, "weight_planes_f16_multi: memset failed");
+            }
+        }
+        const unsigned blocks = (unsigned)std::min<size_t>((most / 16 + 255) / 256 + 1, 256);
+        hipLaunchKernelGGL(absmax_multi_kernel, dim3(blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, b);
     }
+    { const int rc = check_launch("weight_planes_f16_multi.absmax"); if (rc) return rc; }
     return weight_planes_multi_impl(W, N, K, planes, which, amax, count, stream);
 }
 

@@ -482,6 +482,32 @@ def test_weight_planes_batch(dev):
         assert torch.equal(a, b), f"entry {i}"
 
 
+def test_weight_planes_f16_batch(dev):
+    """Two-piece planes of several matrices in one call: each matrix's maximum lands in its slot (neighbouring and
+    scattered slots, more than one launch's worth of entries) and the planes equal the one-matrix calls."""
+    import ctypes
+    shapes = [(1000, 52), (1000, 1000), (48, 1000), (100, 72), (36, 33)] * 4
+    which = [(i % 3) + 1 for i in range(len(shapes))]
+    Ws = [rnd(n, k, seed=160 + i, scale=0.1 * (i + 1)).float().to(dev) for i, (n, k) in enumerate(shapes)]
+    L = nv.lib()
+    sizes = [L.btvae_weight_planes_elems(n, k) for n, k in shapes]
+    one = [torch.full((s,), 0x7FC0, dtype=torch.int16, device=dev) for s in sizes]
+    many = [torch.full((s,), 0x7FC0, dtype=torch.int16, device=dev) for s in sizes]
+    slots = torch.full((64,), 123.0, device=dev)
+    where = list(range(12)) + [20, 40, 41, 42, 50, 13, 14, 63]                  # runs of neighbours and loners
+    for W, (n, k), pl, wh in zip(Ws, shapes, one, which):
+        nv.call("btvae_weight_planes_f16", P(W), k, n, k, P(pl), wh, P(absmax_of(W)))
+    cnt = len(shapes)
+    PA, IA = ctypes.c_void_p * cnt, ctypes.c_int * cnt
+    nv.call("btvae_weight_planes_f16_multi", PA(*[W.data_ptr() for W in Ws]), IA(*[n for n, _ in shapes]), IA(*[k for _, k in shapes]),
+            PA(*[pl.data_ptr() for pl in many]), IA(*which), PA(*[slots[w:w + 1].data_ptr() for w in where]), cnt)
+    for i, (a, b) in enumerate(zip(one, many)):
+        assert torch.equal(a, b), f"entry {i}"
+        assert slots[where[i]].item() == Ws[i].abs().max().item(), f"maximum {i}"
+    untouched = [i for i in range(64) if i not in where]
+    assert bool((slots[untouched] == 123.0).all())
+
+
 def test_matmul_bias_and_mul(dev):
     M, K, N = 260, 100, 1176
     A, B, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
