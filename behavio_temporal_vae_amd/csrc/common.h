@@ -74,12 +74,18 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
-// fold a lane-private non-negative maximum into *out (null: nothing): one integer atomic per wave at most -- non-negative
-// floats order like their bit patterns -- and none when the value already there is at least as large
+// *out = max(*out, m) for non-negative m (non-negative floats order like their bit patterns: an integer atomic), skipped
+// when the slot, read past the CU's own cache, already holds as much: atomics on one address -- and on neighbouring
+// slots, one cache line -- are served one at a time, ~10 ns each, so what matters is how few of them are issued
+__device__ __forceinline__ void amax_commit(float m, float* out) {
+    if (m > 0.f && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
+// fold a lane-private non-negative maximum into *out (null: nothing): one atomic per wave at most
 __device__ __forceinline__ void wave_amax_commit(float m, float* out) {
     if (!out) return;
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f && m > *out) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) amax_commit(m, out);
 }
 __device__ __forceinline__ float amax4(float m, const float4 v) {
     return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));

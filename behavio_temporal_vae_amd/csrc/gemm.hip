@@ -431,7 +431,14 @@ __device__ __forceinline__ void absmax_body(const float* __restrict__ x, size_t 
     } else {
         for (; i < n; i += step) m = fmaxf(m, fabsf(x[i]));
     }
-    wave_amax_commit(m, out);
+    // one atomic per workgroup at most
+    __shared__ float red[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        amax_commit(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), out);
+    }
 }
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) { absmax_body(x, n, out); }
@@ -581,7 +588,7 @@ BTVAE_API int btvae_weight_planes_f16(const float* W, int ldw, int N, int K, voi
 // |x|-maximum of n floats folded into *out, which must hold zero or a maximum to extend.
 BTVAE_API int btvae_absmax(const float* x, long long n, float* out, void* stream) {
     BTVAE_REQUIRE(x && out && n > 0, "absmax: bad arguments");
-    const unsigned blocks = (unsigned)std::min<long long>((n / 16 + 255) / 256 + 1, 1024);
+    const unsigned blocks = (unsigned)std::min<long long>((n / 16 + 255) / 256 + 1, 128);
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, out);
     return check_launch("absmax");
 }
@@ -641,7 +648,7 @@ BTVAE_API int btvae_weight_planes_f16_multi(const float* const* W, const int* N,
                 BTVAE_REQUIRE(hipMemsetAsync(amax[j], 0, sizeof(float) * run, (hipStream_t)stream) == hipSuccess, "weight_planes_f16_multi: memset failed");
             }
         }
-        const unsigned blocks = (unsigned)std::min<size_t>((most / 16 + 255) / 256 + 1, 256);
+        const unsigned blocks = (unsigned)std::min<size_t>((most / 16 + 255) / 256 + 1, 32);
         hipLaunchKernelGGL(absmax_multi_kernel, dim3(blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, b);
     }
     { const int rc = check_launch("weight_planes_f16_multi.absmax"); if (rc) return rc; }
