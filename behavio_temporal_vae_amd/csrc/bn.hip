@@ -89,36 +89,41 @@ __global__ __launch_bounds__(256) void bn_fold_linear_kernel(const float* __rest
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ Wf, float* __restrict__ bf,
-                                                             float* __restrict__ scale, float* __restrict__ shift, int N, int K) {
+                                                             float* __restrict__ scale, float* __restrict__ shift, int N, int K,
+                                                             float* __restrict__ amax_out) {      // null, or where max |Wf| goes
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    float acc = 0.f;
+    const int Kn = n < N ? K : 0;                           // a row past the end does nothing but stays for the reduction
+    float acc = 0.f, vmax = 0.f;
     if (VEC == 4) {
 #pragma unroll 4
-        for (int k = lane * 4; k < K; k += 256) {
+        for (int k = lane * 4; k < Kn; k += 256) {
             const float4 is = *reinterpret_cast<const float4*>(invstd + k), ga = *reinterpret_cast<const float4*>(gamma + k);
             const float4 be = *reinterpret_cast<const float4*>(beta + k), mu = *reinterpret_cast<const float4*>(mean + k);
             const float4 w = *reinterpret_cast<const float4*>(W + (size_t)n * K + k);
             const float4 sc = make_float4(is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w);
             const float4 sh = make_float4(be.x - mu.x * sc.x, be.y - mu.y * sc.y, be.z - mu.z * sc.z, be.w - mu.w * sc.w);
-            *reinterpret_cast<float4*>(Wf + (size_t)n * K + k) = make_float4(w.x * sc.x, w.y * sc.y, w.z * sc.z, w.w * sc.w);
+            const float4 wf = make_float4(w.x * sc.x, w.y * sc.y, w.z * sc.z, w.w * sc.w);
+            *reinterpret_cast<float4*>(Wf + (size_t)n * K + k) = wf;
+            vmax = amax4(vmax, wf);
             acc = fmaf(w.x, sh.x, fmaf(w.y, sh.y, fmaf(w.z, sh.z, fmaf(w.w, sh.w, acc))));
             if (n == 0) { *reinterpret_cast<float4*>(scale + k) = sc; *reinterpret_cast<float4*>(shift + k) = sh; }
         }
     } else {
-        for (int k = lane; k < K; k += 64) {
+        for (int k = lane; k < Kn; k += 64) {
             const float sc = invstd[k] * gamma[k];
             const float sh = beta[k] - mean[k] * sc;
             const float w = W[(size_t)n * K + k];
             Wf[(size_t)n * K + k] = w * sc;
+            vmax = fmaxf(vmax, fabsf(w * sc));
             acc = fmaf(w, sh, acc);
             if (n == 0) { scale[k] = sc; shift[k] = sh; }
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (lane == 0) bf[n] = b[n] + acc;
+    if (lane == 0 && n < N) bf[n] = b[n] + acc;
+    block_amax_commit(vmax, amax_out);
 }
 
 // BatchNorm-backward column sums from the consumers' weight-gradient by-products (btvae_linear_wgrad_affine):
@@ -475,13 +480,14 @@ BTVAE_API int btvae_bn_fold_eval(const float* gamma, const float* beta, const fl
 // BatchNorm's INPUT Y instead:  Wf = W * sc (per input column), bf = b + W sh; also writes sc[K], sh[K].
 BTVAE_API int btvae_bn_fold_linear(const float* W, const float* b, const float* mean, const float* invstd, const float* gamma,
                                    const float* beta, float* Wf, float* bf, float* scale, float* shift, int N, int K, void* stream) {
+    float* amax_out = take_output_maximum();
     BTVAE_REQUIRE(W && b && mean && invstd && gamma && beta && Wf && bf && scale && shift, "bn_fold_linear: null pointer");
     BTVAE_REQUIRE(N > 0 && K > 0, "bn_fold_linear: bad shape N=%d K=%d", N, K);
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (K % 4 == 0 && al(W) && al(Wf) && al(mean) && al(invstd) && al(gamma) && al(beta) && al(scale) && al(shift))
-        hipLaunchKernelGGL((bn_fold_linear_kernel<4>), dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, b, mean, invstd, gamma, beta, Wf, bf, scale, shift, N, K);
+        hipLaunchKernelGGL((bn_fold_linear_kernel<4>), dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, b, mean, invstd, gamma, beta, Wf, bf, scale, shift, N, K, amax_out);
     else
-        hipLaunchKernelGGL((bn_fold_linear_kernel<1>), dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, b, mean, invstd, gamma, beta, Wf, bf, scale, shift, N, K);
+        hipLaunchKernelGGL((bn_fold_linear_kernel<1>), dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, b, mean, invstd, gamma, beta, Wf, bf, scale, shift, N, K, amax_out);
     return check_launch("bn_fold_linear");
 }
 

@@ -87,6 +87,15 @@ __device__ __forceinline__ void wave_amax_commit(float m, float* out) {
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) amax_commit(m, out);
 }
+// the same for a 256-thread workgroup whose every thread arrives: one atomic per workgroup at most
+__device__ __forceinline__ void block_amax_commit(float m, float* out) {
+    __shared__ float amax_red[4];
+    if (!out) return;                                       // uniform
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) amax_commit(fmaxf(fmaxf(amax_red[0], amax_red[1]), fmaxf(amax_red[2], amax_red[3])), out);
+}
 __device__ __forceinline__ float amax4(float m, const float4 v) {
     return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }

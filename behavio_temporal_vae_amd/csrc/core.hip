@@ -95,8 +95,9 @@ BTVAE_API int btvae_init(int device) {
 
 // The next launch, from the calling thread, of a kernel that writes an operand of a later Linear product -- the forward
 // products with ReLU (btvae_linear_relu_stats_fwd*, btvae_linear_relu_affine_fwd*), btvae_bn_apply_fwd,
-// btvae_linear_dgrad_bnbwd*, btvae_bn_relu_bwd, btvae_bn_relu_bwd_apply, btvae_relu_bwd -- also folds the absolute
-// maximum of what it writes (Y / Out / dPre) into the device scalar *amax_out, which must hold zero or a maximum to
+// btvae_linear_dgrad_bnbwd*, btvae_bn_relu_bwd, btvae_bn_relu_bwd_apply, btvae_relu_bwd, btvae_bn_fold_linear,
+// btvae_reparam_kl_fwd -- also folds the absolute maximum of what it writes (Y / Out / dPre / Wf / zc) into the device
+// scalar *amax_out, which must hold zero or a maximum to
 // extend.  Any other entry point of the families above clears the request unused.
 BTVAE_API int btvae_output_maximum(float* amax_out) { t_out_max = amax_out; return 0; }
 

@@ -33,14 +33,15 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* __rest
                                                              const float* __restrict__ cond, float* __restrict__ zc,
                                                              float* __restrict__ klrow, int R, int S, int L, int C,
                                                              int cdiv, int cs_hi, int cs_lo,
-                                                             unsigned long long seed, unsigned long long offset) {
+                                                             unsigned long long seed, unsigned long long offset,
+                                                             float* __restrict__ amax_out) {      // null, or where max |zc| goes
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= R) return;
+    const bool live = r < R;                                // a row past the end does nothing but stays for the reduction
     const int W = L + C;
-    const float* cr = cond + (size_t)(r / cdiv) * cs_hi + (size_t)(r % cdiv) * cs_lo;
-    float kl = 0.f;
-    for (int l = lane; l < L; l += 64) {
+    const float* cr = live ? cond + (size_t)(r / cdiv) * cs_hi + (size_t)(r % cdiv) * cs_lo : cond;
+    float kl = 0.f, vmax = 0.f;
+    for (int l = lane; l < (live ? L : 0); l += 64) {
         const float m = mu[(size_t)r * L + l], sg = sigma[(size_t)r * L + l];
         const float var = sg * sg;
         kl += 0.5f * (var + m * m - 1.f - logf(var));
@@ -49,15 +50,19 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* __rest
             float e;
             if (eps) e = eps[row * L + l];
             else { e = philox_normal(seed, offset, row * L + l); if (eps_out) eps_out[row * L + l] = e; }
-            zc[row * W + l] = m + sg * e;
+            const float z = m + sg * e;
+            zc[row * W + l] = z;
+            vmax = fmaxf(vmax, fabsf(z));
         }
     }
-    for (int j = lane; j < C; j += 64) {
+    for (int j = lane; j < (live ? C : 0); j += 64) {
         const float cv = cr[j];
+        vmax = fmaxf(vmax, fabsf(cv));
         for (int s = 0; s < S; ++s) zc[((size_t)s * R + r) * W + L + j] = cv;
     }
     kl = wave_sum(kl);
-    if (lane == 0) klrow[r] = kl;
+    if (lane == 0 && live) klrow[r] = kl;
+    block_amax_commit(vmax, amax_out);
 }
 
 // gradient wrt the encoder head RAW outputs: (sum_s dz + kw*mu) * dfac_mu, (sum_s dz*eps + kw*(sigma - 1/sigma)) * dfac_sigma
@@ -597,11 +602,12 @@ using namespace btvae;
 BTVAE_API int btvae_reparam_kl_fwd(const float* mu, const float* sigma, const float* eps, float* eps_out, const float* cond,
                                    float* zc, float* klrow, int R, int S, int L, int C, int cdiv, int cs_hi, int cs_lo,
                                    unsigned long long seed, unsigned long long offset, void* stream) {
+    float* amax_out = btvae::take_output_maximum();
     BTVAE_REQUIRE(mu && sigma && zc && klrow && (cond || C == 0), "reparam_kl_fwd: null pointer");
     BTVAE_REQUIRE(R > 0 && S > 0 && L > 0 && C >= 0 && cdiv > 0, "reparam_kl_fwd: bad shape R=%d S=%d L=%d C=%d", R, S, L, C);
     ProfScope ps(PK_REDUCE, (hipStream_t)stream, 0, 4.0 * ((double)S * R * (2 * L + C) + 2.0 * R * L));
     hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, mu, sigma, eps, eps_out, cond, zc, klrow,
-                       R, S, L, C, cdiv, cs_hi, cs_lo, seed, offset);
+                       R, S, L, C, cdiv, cs_hi, cs_lo, seed, offset, amax_out);
     return check_launch("reparam_kl_fwd");
 }
 

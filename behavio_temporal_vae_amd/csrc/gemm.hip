@@ -431,14 +431,7 @@ __device__ __forceinline__ void absmax_body(const float* __restrict__ x, size_t 
     } else {
         for (; i < n; i += step) m = fmaxf(m, fabsf(x[i]));
     }
-    // one atomic per workgroup at most
-    __shared__ float red[4];
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        amax_commit(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), out);
-    }
+    block_amax_commit(m, out);
 }
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) { absmax_body(x, n, out); }

@@ -243,6 +243,14 @@ def _track_output(t: torch.Tensor):
     t._btvae_amax = slot
 
 
+def measure_once(t: torch.Tensor) -> torch.Tensor:
+    """Two-piece mode: take max |t| now and keep it with ``t`` for every product that reads it.  For tensors the caller
+    has just made and will not change (a network's concatenated input, the head gradients of a backward pass)."""
+    if _split_mode() == 2 and getattr(t, "_btvae_amax", None) is None:
+        t._btvae_amax = _amax(t)
+    return t
+
+
 def _operand_maxima(a: Optional[torch.Tensor], b: Optional[torch.Tensor]):
     """Hand the next product its operands' maxima (both or nothing)."""
     if a is not None and b is not None:
@@ -322,6 +330,7 @@ def _linear_operands(lin: torch.nn.Linear, x):
     dev = x.device
     Wf, bf = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
     sc, sh = torch.empty(K, device=dev), torch.empty(K, device=dev)
+    _track_output(Wf)
     nv.call("btvae_bn_fold_linear", P(lin.weight), P(lin.bias), P(x.mean), P(x.invstd), P(x.gamma), P(x.beta), P(Wf), P(bf), P(sc), P(sh), N, K)
     return x.y, Wf, bf, sc, sh
 
@@ -644,7 +653,7 @@ def net_backward(plan: NetPlan, tape: NetTape, draw: Dict[str, torch.Tensor], ne
     head's gradients are enqueued (data-parallel training starts reducing them while the trunk backward runs)."""
     g_trunk = None
     for name, units in plan.heads.items():
-        d = draw[name]
+        d = measure_once(draw[name])              # read by this head's weight gradient and by its dX product
         M, N = d.shape
         dev = d.device
         last = units[-1]
@@ -758,6 +767,7 @@ def reparam_kl(mu, sigma, eps, cond, S: int, three_d: bool, B: int, seed: int = 
         cdiv, hi, lo = B, C, S * C
     else:
         cdiv, hi, lo = R, 0, C
+    _track_output(zc)
     nv.call("btvae_reparam_kl_fwd", P(mu), P(sigma), P(eps), P(eps_out), P(cond), P(zc), P(kl), R, Sl, L, C, cdiv, hi, lo, int(seed), int(offset))
     return zc, kl, (eps if eps is not None else eps_out)
 

@@ -320,14 +320,15 @@ class VAE(torch.nn.Module):
         if tape and not train:
             raise RuntimeError("a training step needs the model in train mode (call model.train())")
         three_d = c is not None and c.ndim == 3
+        E.MAX_SLOTS.fresh()          # every slot this pass uses is zeroed inside it (a captured pass must not inherit slots)
         if c is not None:
             c = self._prep(c, "conditions")
             if c.ndim == 3:
                 if c.shape[1] != S:
                     raise ValueError("Condition samples must be equal to number of posterior MC samples.")
-                enc_in = torch.cat((x.unsqueeze(0).expand(S, B, x.shape[1]), c.transpose(1, 0)), dim=-1).reshape(S * B, -1)
+                enc_in = E.measure_once(torch.cat((x.unsqueeze(0).expand(S, B, x.shape[1]), c.transpose(1, 0)), dim=-1).reshape(S * B, -1).contiguous())
             elif c.ndim == 2:
-                enc_in = torch.cat((x, c), dim=-1)
+                enc_in = E.measure_once(torch.cat((x, c), dim=-1))      # a fresh tensor, read by the forward product and the weight gradient
             else:
                 raise ValueError("Invalid shape for conditions. Must be 2D or 3D tensor.")
         else:

@@ -68,8 +68,9 @@ int btvae_weight_planes_multi(const float* const* W, const int* N, const int* K,
  * btvae_weight_planes_f16_multi computes each matrix's maximum into amax[i] (device scalars) and writes its planes.
  * btvae_output_maximum asks the next launch, from the calling thread, of a kernel that writes an operand of a later
  * Linear product (btvae_linear_relu_stats_fwd*, btvae_linear_relu_affine_fwd*, btvae_bn_apply_fwd,
- * btvae_linear_dgrad_bnbwd*, btvae_bn_relu_bwd, btvae_bn_relu_bwd_apply, btvae_relu_bwd) to fold max|Y / Out / dPre|
- * into *amax_out as btvae_absmax would, without a pass of its own. */
+ * btvae_linear_dgrad_bnbwd*, btvae_bn_relu_bwd, btvae_bn_relu_bwd_apply, btvae_relu_bwd, btvae_bn_fold_linear,
+ * btvae_reparam_kl_fwd) to fold max|Y / Out / dPre / Wf / zc| into *amax_out as btvae_absmax would, without a pass of
+ * its own. */
 int btvae_absmax(const float* x, long long n, float* out, void* stream);
 int btvae_output_maximum(float* amax_out);
 int btvae_gemm_operand_maxima(const float* amax_a, const float* amax_b);

@@ -453,6 +453,22 @@ def test_output_maximum_from_producers(dev, gemm_mode, M, N, K):
         L.btvae_output_maximum(P(slot))
         nv.call("btvae_linear_dgrad_bnbwd", P(dY), P(Wt), None, P(Y), P(mean), P(inv), P(gam), P(sums), M, P(dpre), P(cp), M, K, N)
         assert slot.item() == dpre.abs().max().item()
+    # folded weights and the decoder's z|c rows
+    Wf, bf2, scd, shd = torch.empty(N, K, device=dev), torch.empty(N, device=dev), torch.empty(K, device=dev), torch.empty(K, device=dev)
+    mk, ik = X.mean(0), 1 / torch.sqrt(X.var(0, unbiased=False) + 1e-5)
+    gk, bk = (1 + 0.3 * rnd(K, seed=103)).float().to(dev), rnd(K, seed=104).float().to(dev)
+    slot.zero_()
+    L.btvae_output_maximum(P(slot))
+    nv.call("btvae_bn_fold_linear", P(W), P(b), P(mk), P(ik), P(gk), P(bk), P(Wf), P(bf2), P(scd), P(shd), N, K)
+    assert slot.item() == Wf.abs().max().item() > 0
+    R_, S_, Ld, Cd = 37, 3, 10, 4
+    mu, sg = rnd(R_, Ld, seed=105).float().to(dev), (0.1 + rnd(R_, Ld, seed=106).abs()).float().to(dev)
+    ep, cd = rnd(S_ * R_, Ld, seed=107).float().to(dev), (5 * rnd(R_, Cd, seed=108)).float().to(dev)
+    zc, kl = torch.empty(S_ * R_, Ld + Cd, device=dev), torch.empty(R_, device=dev)
+    slot.zero_()
+    L.btvae_output_maximum(P(slot))
+    nv.call("btvae_reparam_kl_fwd", P(mu), P(sg), P(ep), None, P(cd), P(zc), P(kl), R_, S_, Ld, Cd, R_, 0, Cd, 0, 0)
+    assert slot.item() == zc.abs().max().item() > 0
     # a product that is no producer drops the request
     L.btvae_output_maximum(P(slot))
     D = torch.empty(M, K, device=dev)
