@@ -36,6 +36,7 @@ _SIGS = {
     "btvae_weight_planes_f16_multi": [P, P, P, P, P, P, I, P],
     "btvae_absmax": [P, LL, P, P],
     "btvae_linear_head_fwd": [P, I, P, P, I, F, F, P, P, P, I, I, I, P],
+    "btvae_linear_head_fwd_ws": [P, I, P, P, I, F, F, P, P, P, P, LL, I, I, I, P],
     "btvae_linear_dgrad": [P, P, P, P, I, I, I, I, P],
     "btvae_linear_dgrad_pw": [P, P, P, P, P, I, I, I, I, P],
     "btvae_linear_wgrad": [P, P, I, P, P, LL, I, I, I, I, P],

@@ -338,6 +338,23 @@ __global__ __launch_bounds__(256) void cols_finalize_kernel(const float* __restr
     }
 }
 
+// head non-linearity over the sum of reduction slabs: raw = sum_z slabs[z][i] + bias[i % N]; Out = value(raw),
+// Dfac = d value / d raw, Sq = value^2 (either may be null)
+__global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restrict__ slabs, size_t n, int nslab, size_t stride, int N,
+                                                            const float* __restrict__ bias, GemmArgs p,
+                                                            float* __restrict__ Out, float* __restrict__ Dfac, float* __restrict__ Sq) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        const float raw = slab_sum(slabs, i, nslab, stride) + bias[i % (size_t)N];
+        float val, df;
+        head_value(p, raw, val, df);
+        Out[i] = val;
+        if (Dfac) Dfac[i] = df;
+        if (Sq) Sq[i] = val * val;
+    }
+}
+
 // fp32 matrix W[R][C] (row pitch ldw) -> its high / middle / low bf16 pieces as the tile images the split kernel stages:
 // image F (W rows = output columns, reduction along a row; the forward products): blocks [ceil(R/128)][ceil(C/16)][3][2048],
 // element (row r, k) of a block at s_off(r, k >> 3) + (k & 7); image D (W rows = reduction index; the dX products):
@@ -688,13 +705,31 @@ BTVAE_API int btvae_linear_relu_affine_fwd(const float* X, int ldx, const float*
 
 // Head output layer: raw = X W^T + b; act 0: clamp, 1: clamp(softplus), 2: clamp(relu).
 // Out = value, Dfac = d value / d raw (may be null), Sq = value^2 (may be null).
-BTVAE_API int btvae_linear_head_fwd(const float* X, int ldx, const float* W, const float* b, int act, float lo, float hi,
-                                    float* Out, float* Dfac, float* Sq, int M, int K, int N, void* stream) {
+static int head_fwd_impl(const float* X, int ldx, const float* W, const float* b, int act, float lo, float hi,
+                         float* Out, float* Dfac, float* Sq, float* ws, long long ws_floats, int M, int K, int N, void* stream) {
     BTVAE_REQUIRE(b, "linear_head_fwd: null bias");
     BTVAE_REQUIRE(act >= 0 && act <= 2, "linear_head_fwd: unknown activation %d", act);
     GemmArgs a{}; a.A = X; a.lda = ldx; a.B = W; a.ldb = K; a.C = Out; a.ldc = N; a.M = M; a.N = N; a.K = K;
     a.bias = b; a.C2 = Dfac; a.C3 = Sq; a.act = act; a.lo = lo; a.hi = hi;
     ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    // Few row tiles and a long reduction: one workgroup per tile would walk the whole reduction alone, ~1 us per 16-k
+    // step with nothing to overlap it with (66-73 us for 8-128 workgroups at K = 1000).  Split the reduction over
+    // workgroups into slabs and apply the non-linearity where the slabs are summed.
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    if (ws && M > 0 && N > 0 && tiles <= 128 && K >= 256) {
+        const size_t out_elems = (size_t)M * N;
+        int splits = std::min({512 / tiles, K / 64, (int)((size_t)ws_floats / out_elems)});
+        if (splits >= 2) {
+            GemmArgs g{}; g.A = X; g.lda = ldx; g.B = W; g.ldb = K; g.C = ws; g.ldc = N; g.M = M; g.N = N; g.K = K;
+            g.slab_stride = out_elems;
+            int rc = launch<LAY_K, LAY_K, EPI_BIAS>(g, splits, (hipStream_t)stream, "linear_head_fwd");
+            if (rc) return rc;
+            const int nslab = (K + g.kchunk - 1) / g.kchunk;
+            const int blocks = (int)std::min<size_t>((out_elems + 255) / 256, 2048);
+            hipLaunchKernelGGL(head_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ws, out_elems, nslab, out_elems, N, b, a, Out, Dfac, Sq);
+            return check_launch("linear_head_fwd.finalize");
+        }
+    }
     // narrow heads (N <= 64) in the split mode: 128x64 tile instead of a mostly padded 128x128 one
     const bool vec_in = (ldx % 4 == 0) && (K % 4 == 0) && aligned16(X) && aligned16(W);
     if (g_precision.load(std::memory_order_relaxed) >= 2 && N <= NBN && vec_in && M > 0 && K > 0) {
@@ -703,10 +738,24 @@ BTVAE_API int btvae_linear_head_fwd(const float* X, int ldx, const float* W, con
         a.a_vec = a.b_vec = 1;
         a.c_vec = (N % 4 == 0) && aligned16(Out) && (!Dfac || aligned16(Dfac)) && (!Sq || aligned16(Sq));
         a.tiles_m = (M + BM - 1) / BM; a.tiles_n = 1; a.kchunk = K;
+        (void)btvae::take_output_maximum();
         hipLaunchKernelGGL(gemm_split_head64, dim3((unsigned)a.tiles_m), dim3(256), 0, (hipStream_t)stream, a);
         return check_launch("linear_head_fwd");
     }
     return launch<LAY_K, LAY_K, EPI_HEAD>(a, 1, (hipStream_t)stream, "linear_head_fwd", true);
+}
+
+// Head output layer: raw = X W^T + b; act 0: clamp, 1: clamp(softplus), 2: clamp(relu).
+// Out = value, Dfac = d value / d raw (may be null), Sq = value^2 (may be null).
+BTVAE_API int btvae_linear_head_fwd(const float* X, int ldx, const float* W, const float* b, int act, float lo, float hi,
+                                    float* Out, float* Dfac, float* Sq, int M, int K, int N, void* stream) {
+    return head_fwd_impl(X, ldx, W, b, act, lo, hi, Out, Dfac, Sq, nullptr, 0, M, K, N, stream);
+}
+// The same with a workspace of ws_floats floats (may be null / 0): when the product has few row tiles and a long
+// reduction, the reduction is split over workgroups into slabs held there and summed by a second kernel.
+BTVAE_API int btvae_linear_head_fwd_ws(const float* X, int ldx, const float* W, const float* b, int act, float lo, float hi,
+                                       float* Out, float* Dfac, float* Sq, float* ws, long long ws_floats, int M, int K, int N, void* stream) {
+    return head_fwd_impl(X, ldx, W, b, act, lo, hi, Out, Dfac, Sq, ws, ws_floats, M, K, N, stream);
 }
 
 // dX[M,K] = dY[M,N] W[N,K] (+ R[M,K]).

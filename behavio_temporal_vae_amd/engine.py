@@ -145,6 +145,7 @@ class Workspace:
 
 WS = Workspace()
 WGRAD_WS_FLOATS = 32 * 1024 * 1024
+HEAD_WS_FLOATS = 8 * 1024 * 1024
 
 
 class DropoutFeed:
@@ -449,7 +450,9 @@ def head_forward(u: Unit, x, act: int, lo: float, hi: float, want_dfac: bool, wa
     val = torch.empty(M, N, device=dev)
     dfac = torch.empty(M, N, device=dev) if want_dfac else None
     sq = torch.empty(M, N, device=dev) if want_sq else None
-    nv.call("btvae_linear_head_fwd", P(a), K, P(W), P(b), act, float(lo), float(hi), P(val), P(dfac), P(sq), M, K, N)
+    ws = WS.get("headslab", HEAD_WS_FLOATS, dev) if M <= 128 * 128 else None      # few row tiles: split reduction (see the C side)
+    nv.call("btvae_linear_head_fwd_ws", P(a), K, P(W), P(b), act, float(lo), float(hi), P(val), P(dfac), P(sq),
+            P(ws), ws.numel() if ws is not None else 0, M, K, N)
     own = planes.get(u.lin) if planes else None
     return val, dfac, sq, (x_sc, x_sh, x_pr), ((own if own is not None else _weight_planes(u.lin.weight, PLANES_DX)) if want_dfac else None)
 

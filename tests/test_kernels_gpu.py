@@ -97,6 +97,16 @@ def test_linear_relu_affine_and_head(dev, gemm_mode, M, K, N):
             edge = ((sp - lo).abs() < 1e-4) | ((sp - hi).abs() < 1e-4) | ((raw - 5).abs() < 1e-4)
         dd = (df.cpu().double() - rr.grad).abs()
         assert dd[~edge].max() < 1e-5
+        # with a workspace the reduction is split over workgroups (K >= 256, few row tiles) and the non-linearity applied
+        # where the slabs are summed; without room for two slabs it is the same launch as above
+        for ws in (torch.empty(4 * 1024 * 1024, device=dev), torch.empty(M * N + 5, device=dev)):
+            o2, df2, sq2 = (torch.full((M, N), 7.0, device=dev) for _ in range(3))
+            nv.call("btvae_linear_head_fwd_ws", P(d[0]), K, P(d[1]), P(d[2]), act, lo, hi, P(o2), P(df2), P(sq2), P(ws), ws.numel(), M, K, N)
+            close(o2, val, 1e-5, 2e-6 * math.sqrt(K) + 2e-5, f"head{act} split reduction")
+            close(sq2, val ** 2, 1e-5, 4e-6 * math.sqrt(K) + 2e-5, f"head{act}.sq split reduction")
+            assert (df2.cpu().double() - rr.grad).abs()[~edge].max() < 1e-5
+            if ws.numel() < 2 * M * N:
+                assert torch.equal(o2, o) and torch.equal(df2, df) and torch.equal(sq2, sq)
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 1000, 52), (4096, 100, 1000), (130, 48, 1000), (70, 9, 33)])
