@@ -738,7 +738,8 @@ static int head_fwd_impl(const float* X, int ldx, const float* W, const float* b
         a.a_vec = a.b_vec = 1;
         a.c_vec = (N % 4 == 0) && aligned16(Out) && (!Dfac || aligned16(Dfac)) && (!Sq || aligned16(Sq));
         a.tiles_m = (M + BM - 1) / BM; a.tiles_n = 1; a.kchunk = K;
-        (void)btvae::take_output_maximum();
+        (void)btvae::take_output_maximum();         // requests meant for this launch end here: the narrow kernel serves none
+        t_amax_a = t_amax_b = nullptr;
         hipLaunchKernelGGL(gemm_split_head64, dim3((unsigned)a.tiles_m), dim3(256), 0, (hipStream_t)stream, a);
         return check_launch("linear_head_fwd");
     }
