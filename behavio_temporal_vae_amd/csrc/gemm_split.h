@@ -324,14 +324,6 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && BL == L
     // Register sets: tile j (j >= 1) travels in set j % PD.  Tile 0 goes straight to LDS through set 0.
     SStage sa[PD];
     BStage sb[PD][NB];
-    if (nk > 0) {
-        fetch(0, sa[0], sb[0]);
-        publish_a((smem_raw), sa[0]);
-        publish_b((smem_raw) + BOFF, sb[0]);
-    }
-#pragma unroll
-    for (int j = 1; j <= PD; ++j) fetch(j, sa[j % PD], sb[j % PD]);
-    __syncthreads();
 
     // fragment offsets of this lane (same in every plane and buffer)
     int oa[2], ob[2];
@@ -404,29 +396,55 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && BL == L
     // t+1+PD.  A load therefore has PD iterations of MFMA work (of the resident workgroups) to land.
     // Steady state (every tile touched is a full one): straight-line code, with the split's vector instructions and
     // LDS stores scheduled into the shadow of the 32-cycle MFMAs.
+    // The steady-state loop is entered only from a prologue whose loads are unconditional, in the loop's own order: the
+    // compiler's wait-count insertion merges the load queues of every path into a loop header, and a prologue with
+    // predicated fetches made it wait, at each use of a register set, for all but two of the loads in flight -- half of
+    // the prefetch distance (vmcnt(2) where vmcnt(7) is right; -9 % on all-zero operands, -2.5 % on the forward and weight-
+    // gradient families inside the training step, nothing on random data, where the clock is what limits).
     const int nfull = (kend - kbeg) / SBK;
     int t0 = 0;
-    for (; t0 + 2 * PD < nfull; t0 += PD) {
+    if (nfull > 2 * PD) {
+        s_g2r<AL, true>(p.A, p.lda, m0, p.M, kbeg, kend, tid, sa[0]);
+        fetch_b(kbeg, true, sb[0]);
+        publish_a((smem_raw), sa[0]);
+        publish_b((smem_raw) + BOFF, sb[0]);
 #pragma unroll
-        for (int u = 0; u < PD; ++u) {
-            const int t = t0 + u;
-            const int cur = t & 1;
-            tile_mma((smem_raw + cur * BUF), (smem_raw + cur * BUF) + BOFF);
-            publish_a((smem_raw + (cur ^ 1) * BUF), sa[(u + 1) % PD]);
-            publish_b((smem_raw + (cur ^ 1) * BUF) + BOFF, sb[(u + 1) % PD]);
-            const int k0 = kbeg + (t + 1 + PD) * SBK;
-            s_g2r<AL, true>(p.A, p.lda, m0, p.M, k0, kend, tid, sa[(u + 1) % PD]);
-            fetch_b(k0, true, sb[(u + 1) % PD]);
-            __builtin_amdgcn_sched_group_barrier(0x100, ((AL == LAY_K ? 2 : 4) + (BL == LAY_K ? 2 : 4)) * NPL, 0);   // fragment reads (A, first B sub-tile)
-#pragma unroll
-            for (int k = 0; k < (NPL == 2 ? 12 : 24) * NB; ++k) {
-                if (NB == 2 && k == (NPL == 2 ? 6 : 12)) __builtin_amdgcn_sched_group_barrier(0x100, (BL == LAY_K ? 2 : 4) * NPL, 0);   // second sub-tile's
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, BPRE ? BTVAE_SPLIT_VPM_PRE : BTVAE_SPLIT_VPM, 0);   // a few vector instructions
-                if (k & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // an LDS store
-            }
-            __syncthreads();
+        for (int j = 1; j <= PD; ++j) {
+            s_g2r<AL, true>(p.A, p.lda, m0, p.M, kbeg + j * SBK, kend, tid, sa[j % PD]);
+            fetch_b(kbeg + j * SBK, true, sb[j % PD]);
         }
+        __syncthreads();
+        for (; t0 + 2 * PD < nfull; t0 += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int t = t0 + u;
+                const int cur = t & 1;
+                tile_mma((smem_raw + cur * BUF), (smem_raw + cur * BUF) + BOFF);
+                publish_a((smem_raw + (cur ^ 1) * BUF), sa[(u + 1) % PD]);
+                publish_b((smem_raw + (cur ^ 1) * BUF) + BOFF, sb[(u + 1) % PD]);
+                const int k0 = kbeg + (t + 1 + PD) * SBK;
+                s_g2r<AL, true>(p.A, p.lda, m0, p.M, k0, kend, tid, sa[(u + 1) % PD]);
+                fetch_b(k0, true, sb[(u + 1) % PD]);
+                __builtin_amdgcn_sched_group_barrier(0x100, ((AL == LAY_K ? 2 : 4) + (BL == LAY_K ? 2 : 4)) * NPL, 0);   // fragment reads (A, first B sub-tile)
+#pragma unroll
+                for (int k = 0; k < (NPL == 2 ? 12 : 24) * NB; ++k) {
+                    if (NB == 2 && k == (NPL == 2 ? 6 : 12)) __builtin_amdgcn_sched_group_barrier(0x100, (BL == LAY_K ? 2 : 4) * NPL, 0);   // second sub-tile's
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, BPRE ? BTVAE_SPLIT_VPM_PRE : BTVAE_SPLIT_VPM, 0);   // a few vector instructions
+                    if (k & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // an LDS store
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        if (nk > 0) {
+            fetch(0, sa[0], sb[0]);
+            publish_a((smem_raw), sa[0]);
+            publish_b((smem_raw) + BOFF, sb[0]);
+        }
+#pragma unroll
+        for (int j = 1; j <= PD; ++j) fetch(j, sa[j % PD], sb[j % PD]);
+        __syncthreads();
     }
     // Tail (and short reductions): same steps with bounds checks.
     for (; t0 < nk; t0 += PD) {
