@@ -52,6 +52,11 @@ DOMINANT_KERNEL_HBM_BYTES = {"fp32": 2 * 324658 * 1024 + 304764 * 1024, "fp32_sp
                              "fp32_split2": 2 * 345092 * 1024 + 260049 * 1024}
 
 
+# the same for the eval-mode hidden Linear (relu + affine epilogue) in the two-piece mode at the shapes the scoring and
+# imputation legs run by default: {rows M: bytes} (profiles/r2b_gemm_two_piece_pmc.md)
+EVAL_KERNEL_HBM_BYTES = {819200: 2 * 4989340 * 1024 + 3533180 * 1024, 25000: 2 * 151129 * 1024 + 106064 * 1024}
+
+
 KERNEL_NAME = {"fp32_split": "gemm_split_mfma", "fp32_split2": "gemm_split_mfma", "fp32": "gemm_f32_mfma", "bf16": "gemm_bf16_mfma"}
 PRECISION_NOTE = {
     "fp32_split": "Linear products: fp32 operands as exact 3-way bf16 splits, 6 bf16 MFMAs per product with fp32 accumulation; "
@@ -196,7 +201,10 @@ def _dominant_roofline(nv, precision, what, M, algorithmic_bytes):
     achieved = dom_fl * dom_n / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     return {"bound": "mfma", "kernel": what, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "peak_note": note, "flops_per_launch": dom_fl, "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
-            "traffic": None, "algorithmic_bytes": algorithmic_bytes}
+            "traffic": EVAL_KERNEL_HBM_BYTES.get(M) if precision == "fp32_split2" else None,
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this kernel at this shape, separate passes over this "
+                              "leg (profiles/r2b_gemm_two_piece_pmc.md); not collected live",
+            "algorithmic_bytes": algorithmic_bytes}
 
 
 def scoring_benchmark(dev, rank, world, n_profiles, K, chunk):
