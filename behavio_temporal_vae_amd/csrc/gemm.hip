@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void absmax_multi_kernel(const AbsmaxBatch b) 
 
 // which kernels exist with two fp16 pieces per operand value: the Linear layers' products
 template <int AL, int BL, int EPI> constexpr bool has_twopiece() {
-    return (AL == LAY_K && BL == LAY_K && (EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE)) ||
+    return (AL == LAY_K && BL == LAY_K && (EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE || EPI == EPI_HEAD)) ||
            (AL == LAY_K && BL == LAY_M && (EPI == EPI_PLAIN || EPI == EPI_BNBWD || EPI == EPI_GSTATS)) ||
            (AL == LAY_M && BL == LAY_M && EPI == EPI_PLAIN);
 }

@@ -11,7 +11,7 @@ constexpr int NBN = 64;                       // block columns
 constexpr int NPLANE_B = NBN * SBK;           // bf16 elements per B plane (2 KiB)
 constexpr int NEPL = 68;                      // row pitch (floats) of the epilogue's LDS image
 
-__global__ __launch_bounds__(256, 2) void gemm_split_head64(const GemmArgs p) {
+__global__ __launch_bounds__(256, 4) void gemm_split_head64(const GemmArgs p) {
     constexpr int PD = 2;
     // per buffer: A planes 3 x 2048, B planes 3 x 1024 bf16 = 18 KiB; the epilogue image [128][68] fp32 fits in both
     __shared__ __attribute__((aligned(16))) __bf16 smem[2][3 * SPLANE + 3 * NPLANE_B];
@@ -52,46 +52,89 @@ __global__ __launch_bounds__(256, 2) void gemm_split_head64(const GemmArgs p) {
         b_fetch(k0, b);
     };
 
+    // the same without predicates, for k-tiles that lie wholly inside K: rows past N re-read the last row (they feed
+    // accumulator columns that are never stored)
+    auto b_fetch_full = [&](int k0, float (&v)[4]) {
+        const int gr = min(tid >> 2, p.N - 1), gk = k0 + ((tid & 3) << 2);
+        const float4 a = *reinterpret_cast<const float4*>(p.B + (size_t)gr * p.ldb + gk);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    };
+
     SStage sa[PD];
     float sb[PD][4];
-    if (nk > 0) {
-        fetch(0, sa[0], sb[0]);
-        s_r2s<LAY_K>(smem[0], tid, sa[0]);
-        b_store(smem[0] + 3 * SPLANE, sb[0]);
-    }
-#pragma unroll
-    for (int j = 1; j <= PD; ++j) fetch(j, sa[j % PD], sb[j % PD]);
-    __syncthreads();
 
     const int oa = s_off(wid * 32 + li, lh);
     int ob[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) ob[j] = s_off(j * 32 + li, lh);
 
-    for (int t0 = 0; t0 < nk; t0 += PD) {
+    auto tile_mma = [&](int cur) {
+        const __bf16* As = smem[cur];
+        const __bf16* Bs = smem[cur] + 3 * SPLANE;
+        sbf16x8 a[3], b[3][2];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            a[pl] = *reinterpret_cast<const sbf16x8*>(As + pl * SPLANE + oa);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[pl][j] = *reinterpret_cast<const sbf16x8*>(Bs + pl * NPLANE_B + ob[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {      // small terms first
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0][j], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2][j], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1][j], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0][j], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1][j], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][j], acc[j], 0, 0, 0);
+        }
+    };
+
+    // Steady state entered only from an unpredicated prologue (see gemm_split.h: a predicated path into the loop header
+    // makes the compiler's wait counts drain the load queue at every use).
+    const int nfull = p.K / SBK;
+    int t0 = 0;
+    if (nfull > 2 * PD) {
+        s_g2r<LAY_K, true>(p.A, p.lda, m0, p.M, 0, p.K, tid, sa[0]);
+        b_fetch_full(0, sb[0]);
+        s_r2s<LAY_K>(smem[0], tid, sa[0]);
+        b_store(smem[0] + 3 * SPLANE, sb[0]);
+#pragma unroll
+        for (int j = 1; j <= PD; ++j) {
+            s_g2r<LAY_K, true>(p.A, p.lda, m0, p.M, j * SBK, p.K, tid, sa[j % PD]);
+            b_fetch_full(j * SBK, sb[j % PD]);
+        }
+        __syncthreads();
+        for (; t0 + 2 * PD < nfull; t0 += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int t = t0 + u;
+                const int cur = t & 1;
+                tile_mma(cur);
+                s_r2s<LAY_K>(smem[cur ^ 1], tid, sa[(u + 1) % PD]);
+                b_store(smem[cur ^ 1] + 3 * SPLANE, sb[(u + 1) % PD]);
+                const int k0 = (t + 1 + PD) * SBK;
+                s_g2r<LAY_K, true>(p.A, p.lda, m0, p.M, k0, p.K, tid, sa[(u + 1) % PD]);
+                b_fetch_full(k0, sb[(u + 1) % PD]);
+                __syncthreads();
+            }
+        }
+    } else {
+        if (nk > 0) {
+            fetch(0, sa[0], sb[0]);
+            s_r2s<LAY_K>(smem[0], tid, sa[0]);
+            b_store(smem[0] + 3 * SPLANE, sb[0]);
+        }
+#pragma unroll
+        for (int j = 1; j <= PD; ++j) fetch(j, sa[j % PD], sb[j % PD]);
+        __syncthreads();
+    }
+    for (; t0 < nk; t0 += PD) {
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
             const int t = t0 + u;
             if (t < nk) {
                 const int cur = t & 1;
-                const __bf16* As = smem[cur];
-                const __bf16* Bs = smem[cur] + 3 * SPLANE;
-                sbf16x8 a[3], b[3][2];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    a[pl] = *reinterpret_cast<const sbf16x8*>(As + pl * SPLANE + oa);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) b[pl][j] = *reinterpret_cast<const sbf16x8*>(Bs + pl * NPLANE_B + ob[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {      // small terms first
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0][j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2][j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1][j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0][j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1][j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0][j], acc[j], 0, 0, 0);
-                }
+                tile_mma(cur);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < nk) {
                     s_r2s<LAY_K>(smem[cur ^ 1], tid, sa[(u + 1) % PD]);

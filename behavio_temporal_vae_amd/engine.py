@@ -451,6 +451,8 @@ def head_forward(u: Unit, x, act: int, lo: float, hi: float, want_dfac: bool, wa
     dfac = torch.empty(M, N, device=dev) if want_dfac else None
     sq = torch.empty(M, N, device=dev) if want_sq else None
     ws = WS.get("headslab", HEAD_WS_FLOATS, dev) if M <= 128 * 128 else None      # few row tiles: split reduction (see the C side)
+    if N > 64 and ws is None:                 # the 128-wide head kernel has a two-piece form; the narrow one (N <= 64) is
+        _operand_maxima(_amax(a), _amax(W))   # memory-bound and the split-reduction one latency-bound
     nv.call("btvae_linear_head_fwd_ws", P(a), K, P(W), P(b), act, float(lo), float(hi), P(val), P(dfac), P(sq),
             P(ws), ws.numel() if ws is not None else 0, M, K, N)
     own = planes.get(u.lin) if planes else None
