@@ -35,6 +35,7 @@ _SIGS = {
     "btvae_weight_planes_f16": [P, I, I, I, P, I, P, P],
     "btvae_weight_planes_f16_multi": [P, P, P, P, P, P, I, P],
     "btvae_absmax": [P, LL, P, P],
+    "btvae_slots_zero": [P, I, P],
     "btvae_linear_head_fwd": [P, I, P, P, I, F, F, P, P, P, I, I, I, P],
     "btvae_linear_head_fwd_ws": [P, I, P, P, I, F, F, P, P, P, P, LL, I, I, I, P],
     "btvae_linear_dgrad": [P, P, P, P, I, I, I, I, P],

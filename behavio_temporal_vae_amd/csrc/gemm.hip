@@ -453,6 +453,16 @@ __device__ __forceinline__ void absmax_body(const float* __restrict__ x, size_t 
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) { absmax_body(x, n, out); }
 
+// Maximum slots are cleared by a kernel, never by hipMemsetAsync: under stream capture a memset becomes a memset node, and
+// replays of a training step captured with such nodes in front of the atomics left slots holding earlier contents now and
+// then (scales far too small, gradients flushed to zero, training diverging after some hundred replays).  Kernel nodes
+// keep their stream order.
+struct SlotRuns { float* p[16]; int n[16]; };
+__global__ __launch_bounds__(64) void slots_zero_kernel(const SlotRuns r) {
+    float* p = r.p[blockIdx.x];
+    for (int i = threadIdx.x; i < r.n[blockIdx.x]; i += 64) p[i] = 0.f;
+}
+
 // several tensors in one launch: blockIdx.y selects the entry
 struct AbsmaxBatch { const float* x[16]; float* out[16]; size_t n[16]; };
 __global__ __launch_bounds__(256) void absmax_multi_kernel(const AbsmaxBatch b) { absmax_body(b.x[blockIdx.y], b.n[blockIdx.y], b.out[blockIdx.y]); }
@@ -603,6 +613,14 @@ BTVAE_API int btvae_absmax(const float* x, long long n, float* out, void* stream
     return check_launch("absmax");
 }
 
+// Clear n maximum slots with a kernel launch (see slots_zero_kernel: safe inside a captured graph, which a memset is not).
+BTVAE_API int btvae_slots_zero(float* slots, int n, void* stream) {
+    BTVAE_REQUIRE(slots && n > 0, "slots_zero: bad arguments");
+    SlotRuns r{}; r.p[0] = slots; r.n[0] = n;
+    hipLaunchKernelGGL(slots_zero_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, r);
+    return check_launch("slots_zero");
+}
+
 // Absolute maxima (device scalars) of the A and B operand tensors of the NEXT product launched from the calling thread;
 // that launch consumes them.  In precision mode 3 a Linear-layer product that has both runs with two fp16 pieces per
 // value; one without, or any product in another mode, ignores them.  Each maximum must cover every element the product
@@ -651,13 +669,15 @@ BTVAE_API int btvae_weight_planes_f16_multi(const float* const* W, const int* N,
             BTVAE_REQUIRE(W[j] && amax[j] && N[j] > 0 && K[j] > 0, "weight_planes_f16_multi: entry %d: bad arguments", j);
             b.x[i] = W[j]; b.out[i] = amax[j]; b.n[i] = (size_t)N[j] * K[j];
             most = std::max(most, b.n[i]);
-            // slots that are neighbours in memory are cleared together
-            if (i == 0 || amax[j] != amax[j - 1] + 1) {
-                int run = 1;
-                while (i + run < n && amax[j + run] == amax[j] + run) ++run;
-                BTVAE_REQUIRE(hipMemsetAsync(amax[j], 0, sizeof(float) * run, (hipStream_t)stream) == hipSuccess, "weight_planes_f16_multi: memset failed");
-            }
         }
+        SlotRuns runs{};
+        int nruns = 0;
+        for (int i = 0; i < n; ++i) {                        // slots that are neighbours in memory are cleared as one run
+            const int j = base + i;
+            if (i > 0 && amax[j] == amax[j - 1] + 1) ++runs.n[nruns - 1];
+            else { runs.p[nruns] = amax[j]; runs.n[nruns] = 1; ++nruns; }
+        }
+        hipLaunchKernelGGL(slots_zero_kernel, dim3((unsigned)nruns), dim3(64), 0, (hipStream_t)stream, runs);
         const unsigned blocks = (unsigned)std::min<size_t>((most / 16 + 255) / 256 + 1, 32);
         hipLaunchKernelGGL(absmax_multi_kernel, dim3(blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, b);
     }

@@ -212,7 +212,8 @@ class _MaxSlots:
 
     def take(self, dev) -> torch.Tensor:
         if self.chunk is None or self.used == self.CHUNK or self.chunk.device != dev:
-            self.chunk, self.used = torch.zeros(self.CHUNK, device=dev), 0
+            self.chunk, self.used = torch.zeros(self.CHUNK, device=dev), 0      # a fill kernel (a memset node in a captured
+                                                                                 # graph does not hold its place: btvae_slots_zero)
         self.used += 1
         return self.chunk[self.used - 1:self.used]
 

@@ -72,6 +72,7 @@ int btvae_weight_planes_multi(const float* const* W, const int* N, const int* K,
  * btvae_reparam_kl_fwd) to fold max|Y / Out / dPre / Wf / zc| into *amax_out as btvae_absmax would, without a pass of
  * its own. */
 int btvae_absmax(const float* x, long long n, float* out, void* stream);
+int btvae_slots_zero(float* slots, int n, void* stream);
 int btvae_output_maximum(float* amax_out);
 int btvae_gemm_operand_maxima(const float* amax_a, const float* amax_b);
 int btvae_weight_planes_f16(const float* W, int ldw, int N, int K, void* planes, int which, const float* amax, void* stream);

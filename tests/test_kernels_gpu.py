@@ -534,6 +534,43 @@ def test_weight_planes_f16_batch(dev):
     assert bool((slots[untouched] == 123.0).all())
 
 
+def test_weight_maxima_retaken_by_every_graph_replay(dev):
+    """``btvae_weight_planes_f16_multi`` captured into a HIP graph: every replay clears the maximum slots (with a kernel:
+    a captured memset does not reliably run in its place) and takes the maxima of the weights as they are then --
+    smaller ones included -- and ``btvae_slots_zero`` clears a run of slots."""
+    import ctypes
+    shapes = [(1000, 52), (1000, 1000), (48, 1000)]
+    Ws = [rnd(n, k, seed=170 + i).float().to(dev) for i, (n, k) in enumerate(shapes)]
+    L = nv.lib()
+    planes = [torch.zeros(L.btvae_weight_planes_elems(n, k), dtype=torch.int16, device=dev) for n, k in shapes]
+    slots = torch.full((8,), 5.0e4, device=dev)
+    cnt = len(shapes)
+    PA, IA = ctypes.c_void_p * cnt, ctypes.c_int * cnt
+    args = (PA(*[W.data_ptr() for W in Ws]), IA(*[n for n, _ in shapes]), IA(*[k for _, k in shapes]),
+            PA(*[pl.data_ptr() for pl in planes]), IA(3, 3, 2), PA(slots[1:2].data_ptr(), slots[2:3].data_ptr(), slots[6:7].data_ptr()), cnt)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        nv.call("btvae_weight_planes_f16_multi", *args)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        nv.call("btvae_weight_planes_f16_multi", *args)
+    for factor in (1.0, 1 / 64, 512.0, 1 / 4096, 3.0):
+        for W in Ws:
+            W.mul_(factor)
+        graph.replay()
+        got = slots.cpu()
+        for i, j in enumerate((1, 2, 6)):
+            assert got[j].item() == Ws[i].abs().max().item(), (factor, i)
+        assert bool((got[[0, 3, 4, 5, 7]] == 5.0e4).all())
+        one = torch.zeros_like(planes[1])
+        nv.call("btvae_weight_planes_f16", P(Ws[1]), 1000, 1000, 1000, P(one), 3, P(slots[2:3]))
+        assert torch.equal(one, planes[1]), factor
+    nv.call("btvae_slots_zero", P(slots[2:]), 5)
+    assert slots.cpu().tolist()[2:7] == [0.0] * 5 and slots[1].item() > 0 and slots[7].item() == 5.0e4
+
+
 def test_matmul_bias_and_mul(dev):
     M, K, N = 260, 100, 1176
     A, B, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)

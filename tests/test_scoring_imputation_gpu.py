@@ -367,6 +367,36 @@ def test_training_entry_point_synthetic(dev, tmp_path):
     assert set(mk) == {"latent_dim", "distribution_dict", "_"}
 
 
+def test_long_training_run_replayed_equals_eager(dev, tmp_path, monkeypatch):
+    """A thousand iterations of ``main(config0)`` at its shipped size, with validation passes in between, once with the
+    training step replayed from its HIP graph and once eager: the logged ELBO and KL agree all the way (a replay that
+    keeps anything from an earlier replay -- operand maxima in the two-piece GEMM mode above all -- degrades training
+    only after several hundred iterations, which the few-step tests cannot see), and the posterior has not collapsed."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    from behavio_temporal_vae_amd import vae_models as VM
+    spec = importlib.util.spec_from_file_location("training_entry", os.path.join(ROOT, "scripts", "training.py"))
+    tr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tr)
+    logs = {}
+    for mode in ("auto", "0"):
+        monkeypatch.setenv("BTVAE_STEP_GRAPH", mode)
+        cfg = tr.load_config(os.path.join(ROOT, "config_files", "config0.json"))
+        cfg["train"].update({"epochs": 1, "device": "cuda:0", "save_epoch_freq": None, "verbose_freq": 250})
+        cfg["save_dir"] = str(tmp_path / mode)
+        os.makedirs(cfg["save_dir"])
+        seen = logs.setdefault(mode, [])
+        monkeypatch.setattr(VM.VAE, "train_verbose", lambda self, itx, loss, pbar=None, seen=seen: seen.append((itx, float(loss["elbo"]), float(loss["kl"]))))
+        torch.manual_seed(2112)
+        model = tr.main(cfg, n_train=1000 * cfg["train"]["batch_size"], n_val=8192)
+        assert (len(model.__dict__.get("_step_graphs", {})) > 0) == (mode == "auto")
+    a, b = np.array(logs["auto"]), np.array(logs["0"])
+    assert a.shape == b.shape and a.shape[0] >= 4 and (a[:, 0] == b[:, 0]).all()
+    assert np.abs(a[:, 1:] - b[:, 1:]).max() <= 5e-3 * np.abs(b[:, 1:]).max(), (a, b)
+    assert a[-1, 1] > a[0, 1] and a[-1, 2] > 5.0, a
+
+
 def test_training_entry_point_on_arrays(dev, tmp_path):
     """``scripts/training.py --train_npz/--val_npz``: real arrays instead of the synthetic fallback, including a
     day-before profile tag (identity) next to the calendar tags, so the condition width follows the data (2+2+24)."""
