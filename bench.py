@@ -630,7 +630,7 @@ def main():
                          "measured_in": ("5 eager steps right after the timed region (the timed steps are replayed from a HIP graph)" if graphed
                                          else "the timed region"),
                          "traffic": DOMINANT_KERNEL_HBM_BYTES.get(main_precision) if (S * B == 65536) else None,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this kernel at this shape, separate passes: profiles/r2_gemm_two_piece_pmc.md (fp32_split2), profiles/r1_gemm_fwd_pmc.md (other modes); not collected live",
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this kernel at this shape, separate passes: profiles/r2b_gemm_two_piece_pmc.md (fp32_split2), profiles/r1_gemm_fwd_pmc.md (other modes); not collected live",
                          "algorithmic_bytes": 4.0 * (S * B * 1000 + 1000 * 1000 + S * B * 1000),
                          "fwd_family_tflops": fwd_fl / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else None,
                          "all_gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None,

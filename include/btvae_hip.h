@@ -58,7 +58,9 @@ int btvae_weight_planes_multi(const float* const* W, const int* N, const int* K,
                               int count, void* stream);
 
 /* Mode 3 (no counterpart in the reference: torch.nn.Linear multiplies fp32 values, src/submodels.py:15-17).
- * btvae_absmax folds max|x| over n floats into the device scalar *out, which must hold zero or a maximum to extend.
+ * btvae_absmax folds max|x| over n floats into the device scalar *out, which must hold zero or a maximum to extend;
+ * btvae_slots_zero clears n neighbouring slots with a kernel launch (use it rather than hipMemsetAsync on a stream that may
+ * be under capture: a memset node was seen not to keep its place among a graph's kernel nodes).
  * btvae_gemm_operand_maxima names the device scalars holding the maxima of the A operand (activations or gradients)
  * and the B operand (weight, or activations for a weight gradient) of the NEXT product launched from the calling
  * thread; that launch consumes them.  Each must be final on the product's stream and cover every element the product
