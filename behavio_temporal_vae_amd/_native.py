@@ -30,6 +30,7 @@ _SIGS = {
     "btvae_linear_relu_stats_fwd_pw": [P, I, P, P, P, P, P, I, I, I, P],
     "btvae_linear_relu_affine_fwd": [P, I, P, P, P, P, P, P, I, I, I, P],
     "btvae_linear_relu_affine_fwd_pw": [P, I, P, P, P, P, P, P, P, I, I, I, P],
+    "btvae_linear_relu_affine_fwd_pw_ld": [P, I, P, P, P, P, P, P, I, P, I, I, I, I, P],
     "btvae_weight_planes": [P, I, I, I, P, I, P],
     "btvae_weight_planes_multi": [P, P, P, P, P, I, P],
     "btvae_weight_planes_f16": [P, I, I, I, P, I, P, P],
@@ -155,6 +156,16 @@ def ptr(t):
         return None
     if not t.is_contiguous():
         raise RuntimeError("non-contiguous tensor passed to the HIP library")
+    return c_void_p(t.data_ptr())
+
+
+def ptr_rows(t):
+    """Device pointer of a 2-D tensor whose rows are contiguous but may be a pitch apart (``t.stride(0)`` floats); the
+    callee is given that pitch as the leading dimension."""
+    if t is None:
+        return None
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        raise RuntimeError("tensor passed to the HIP library is not a matrix of contiguous rows")
     return c_void_p(t.data_ptr())
 
 

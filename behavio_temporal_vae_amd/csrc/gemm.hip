@@ -710,13 +710,21 @@ BTVAE_API int btvae_linear_relu_stats_fwd(const float* X, int ldx, const float* 
 }
 
 // Out = relu(X W^T + b) * scale + shift (+ R): Linear+ReLU+eval-mode BatchNorm(+residual) in one pass.
-BTVAE_API int btvae_linear_relu_affine_fwd_pw(const float* X, int ldx, const float* W, const void* Wplanes, const float* b, const float* scale,
-                                              const float* shift, const float* R, float* Out, int M, int K, int N, void* stream) {
+// `_ld`: the residual input and the output with row pitches of their own (ldr, ldo >= N).  Rows that start on 128-byte
+// lines (a pitch that is a multiple of 32 floats where N = 1000 is not) are read by the next product in whole sectors:
+// -11 % on that product at M = 65536, N = K = 1000 with only its activation operand padded.
+BTVAE_API int btvae_linear_relu_affine_fwd_pw_ld(const float* X, int ldx, const float* W, const void* Wplanes, const float* b, const float* scale,
+                                                 const float* shift, const float* R, int ldr, float* Out, int ldo, int M, int K, int N, void* stream) {
     BTVAE_REQUIRE(b, "linear_relu_affine_fwd: null bias");
-    GemmArgs a{}; a.A = X; a.lda = ldx; a.B = W; a.ldb = K; a.C = Out; a.ldc = N; a.M = M; a.N = N; a.K = K;
-    a.bias = b; a.scale = scale; a.shift = shift; a.R = R; a.ldr = N; set_planes(a, Wplanes, N, K, false);
+    BTVAE_REQUIRE(ldo >= N && (!R || ldr >= N), "linear_relu_affine_fwd: row pitch below N = %d (ldr %d, ldo %d)", N, ldr, ldo);
+    GemmArgs a{}; a.A = X; a.lda = ldx; a.B = W; a.ldb = K; a.C = Out; a.ldc = ldo; a.M = M; a.N = N; a.K = K;
+    a.bias = b; a.scale = scale; a.shift = shift; a.R = R; a.ldr = ldr; set_planes(a, Wplanes, N, K, false);
     ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     return launch<LAY_K, LAY_K, EPI_RELU_AFFINE>(a, 1, (hipStream_t)stream, "linear_relu_affine_fwd", true);
+}
+BTVAE_API int btvae_linear_relu_affine_fwd_pw(const float* X, int ldx, const float* W, const void* Wplanes, const float* b, const float* scale,
+                                              const float* shift, const float* R, float* Out, int M, int K, int N, void* stream) {
+    return btvae_linear_relu_affine_fwd_pw_ld(X, ldx, W, Wplanes, b, scale, shift, R, N, Out, N, M, K, N, stream);
 }
 BTVAE_API int btvae_linear_relu_affine_fwd(const float* X, int ldx, const float* W, const float* b, const float* scale,
                                            const float* shift, const float* R, float* Out, int M, int K, int N, void* stream) {

@@ -23,6 +23,7 @@ import torch
 from . import _native as nv
 
 P = nv.ptr
+PR = nv.ptr_rows
 BN_EPS_DEFAULT = 1e-5
 
 
@@ -185,6 +186,7 @@ BWD_SUMS_IN_DGRAD = not os.environ.get('BTVAE_NO_DGRAD_SUMS')   # reduction pass
 BWD_FUSED_INTO_CONSUMER = not os.environ.get('BTVAE_NO_FUSED_BWD')   # ... and run their BatchNorm backward in the epilogue of the last such Linear's dX product
 
 
+PITCHED_EVAL = not os.environ.get('BTVAE_NO_PITCHED_EVAL')    # eval-mode activations in line-aligned rows (_rows_on_lines)
 PRESPLIT_WEIGHTS = not os.environ.get('BTVAE_NO_PRESPLIT')   # split mode: weights split into bf16 planes once per pass
 
 
@@ -322,6 +324,21 @@ def _plan_planes(plan: "NetPlan", backward: bool) -> Dict[torch.nn.Linear, torch
     return out
 
 
+ROW_LINE_FLOATS = 32       # a 128-byte line
+
+
+def _rows_on_lines(M: int, N: int, dev) -> torch.Tensor:
+    """An [M, N] activation buffer whose rows start on 128-byte lines (pitch = N rounded up to 32 floats; a view when
+    that pads).  The products read 64 bytes of each of 128 rows per step: from rows of 4000 bytes those pieces straddle
+    sectors and lines (-11 % on the N = K = 1000 product with line-aligned rows).  Only the eval-mode chain keeps its
+    activations this way: every kernel that touches them takes a row pitch (``btvae_linear_relu_affine_fwd_pw_ld``, the
+    head product's ``ldx``)."""
+    pitch = -(-N // ROW_LINE_FLOATS) * ROW_LINE_FLOATS
+    if pitch == N or not PITCHED_EVAL:
+        return torch.empty(M, N, device=dev)
+    return torch.empty(M, pitch, device=dev)[:, :N]
+
+
 def _linear_operands(lin: torch.nn.Linear, x):
     """(A, W, b, scale, shift) of ``lin`` applied to ``x``: a tensor as is, a Normed input through folded weights."""
     if not isinstance(x, Normed):
@@ -423,14 +440,15 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         if saved is not None:
             saved.append(Saved(x, y, None, None, keep, ks, 0, x_sc, x_sh, x_pr, None, x_src, w_planes=wp_bwd))
     else:
-        out = torch.empty(M, N, device=dev)
+        out = _rows_on_lines(M, N, dev)
         scale = shift = None
         if u.bn is not None:
             scale, shift = torch.empty(N, device=dev), torch.empty(N, device=dev)
             nv.call("btvae_bn_fold_eval", P(u.bn.weight), P(u.bn.bias), P(u.bn.running_mean), P(u.bn.running_var), float(u.bn.eps), P(scale), P(shift), N)
         _operand_maxima(_amax(x), _planes_amax(wp, W))
         _track_output(out)
-        nv.call("btvae_linear_relu_affine_fwd_pw", P(x), K, P(W), P(wp), P(b), P(scale), P(shift), P(x) if u.residual else None, P(out), M, K, N)
+        nv.call("btvae_linear_relu_affine_fwd_pw_ld", PR(x), x.stride(0), P(W), P(wp), P(b), P(scale), P(shift),
+                PR(x) if u.residual else None, x.stride(0), PR(out), out.stride(0), M, K, N)
     return out
 
 
@@ -454,7 +472,7 @@ def head_forward(u: Unit, x, act: int, lo: float, hi: float, want_dfac: bool, wa
     ws = WS.get("headslab", HEAD_WS_FLOATS, dev) if M <= 128 * 128 else None      # few row tiles: split reduction (see the C side)
     if N > 64 and ws is None:                 # the 128-wide head kernel has a two-piece form; the narrow one (N <= 64) is
         _operand_maxima(_amax(a), _amax(W))   # memory-bound and the split-reduction one latency-bound
-    nv.call("btvae_linear_head_fwd_ws", P(a), K, P(W), P(b), act, float(lo), float(hi), P(val), P(dfac), P(sq),
+    nv.call("btvae_linear_head_fwd_ws", PR(a), a.stride(0), P(W), P(b), act, float(lo), float(hi), P(val), P(dfac), P(sq),
             P(ws), ws.numel() if ws is not None else 0, M, K, N)
     own = planes.get(u.lin) if planes else None
     return val, dfac, sq, (x_sc, x_sh, x_pr), ((own if own is not None else _weight_planes(u.lin.weight, PLANES_DX)) if want_dfac else None)

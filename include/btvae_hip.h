@@ -92,6 +92,10 @@ int btvae_linear_relu_affine_fwd(const float* X, int ldx, const float* W, const 
                                  const float* shift, const float* R, float* Out, int M, int K, int N, void* stream);
 int btvae_linear_relu_affine_fwd_pw(const float* X, int ldx, const float* W, const void* Wplanes, const float* b, const float* scale,
                                     const float* shift, const float* R, float* Out, int M, int K, int N, void* stream);
+/* The same with row pitches for the residual input and the output (ldr, ldo >= N): a chain of eval-mode layers keeps its
+ * activations in buffers whose rows start on 128-byte lines. */
+int btvae_linear_relu_affine_fwd_pw_ld(const float* X, int ldx, const float* W, const void* Wplanes, const float* b, const float* scale,
+                                       const float* shift, const float* R, int ldr, float* Out, int ldo, int M, int K, int N, void* stream);
 /* Head output Linear + non-linearity (src/submodels.py:102-104,156-157): act 0 clamp(raw,lo,hi),
  * 1 clamp(softplus(raw, threshold 5),lo,hi) (src/utils.py:10), 2 clamp(relu(raw),lo,hi).
  * Dfac = d Out / d raw and Sq = Out^2 are optional outputs (NULL to skip). */

@@ -34,6 +34,11 @@ def main():
     b = torch.randn(N, device=dev, generator=g)
     if os.environ.get("BTVAE_BENCH_ZERO"):          # all-zero operands: the rate the instruction stream allows when no datapath toggles
         X.zero_(); W.zero_()
+    ldx = int(os.environ.get("BTVAE_BENCH_LDX", K))        # row pitch of the forward products' activation operand
+    Xf = X                                                 # the same values in a buffer of that pitch (dense [M, ldx])
+    if ldx != K:
+        Xf = torch.zeros(M, ldx, device=dev)
+        Xf[:, :K] = X
     Y = torch.empty(M, N, device=dev)
     part = torch.empty((M + 127) // 128, 2, max(N, K), device=dev)
     dX = torch.empty(M, K, device=dev)
@@ -85,7 +90,7 @@ def main():
         "gstats_big": lambda: nv.call("btvae_linear_dgrad_gstats_pw", P(Y), P(W), P(planes), P(X), P(X), P(mean), P(inv), P(dX), P(part), M, N, K),
         "bnbwd_big": lambda: nv.call("btvae_linear_dgrad_bnbwd_pw", P(Y), P(W), P(planes), P(X), P(X), P(mean), P(inv), P(gam), P(sums2), M, P(dX), P(colpart), M, N, K),
         "head_fwd": lambda: nv.call("btvae_linear_head_fwd", P(X), K, P(Wh), P(b), 2, 1e-4, 0.62, P(hv), P(hd), P(hs), M, K, V),
-        "fwd_pw": lambda: nv.call("btvae_linear_relu_stats_fwd_pw", P(X), K, P(W), P(planes), P(b), P(Y), P(part), M, K, N),
+        "fwd_pw": lambda: nv.call("btvae_linear_relu_stats_fwd_pw", P(Xf), ldx, P(W), P(planes), P(b), P(Y), P(part), M, K, N),
         "dgrad_pw": lambda: nv.call("btvae_linear_dgrad_pw", P(Y), P(W), P(planes), None, P(dX), K, M, N, K),
         "fwd": lambda: nv.call("btvae_linear_relu_stats_fwd", P(X), K, P(W), P(b), P(Y), P(part), M, K, N),
         "dgrad": lambda: nv.call("btvae_linear_dgrad", P(Y), P(W), None, P(dX), K, M, N, K),
@@ -93,7 +98,7 @@ def main():
     }
     Y.normal_(generator=g)         # the dX entries read Y as their A operand before any forward entry has written it
     a_of = {"headout_bnbwd": (dV, Wh), "headout_plain": (dV, Wh), "headout_gstats": (dV, Wh), "gstats_big": (Y, W), "bnbwd_big": (Y, W),
-            "fwd_pw": (X, W), "dgrad_pw": (Y, W), "fwd": (X, W), "dgrad": (Y, W), "wgrad": (Y, X)}
+            "fwd_pw": (Xf, W), "dgrad_pw": (Y, W), "fwd": (X, W), "dgrad": (Y, W), "wgrad": (Y, X)}
     if N != K:
         ops = {k: v for k, v in ops.items() if k in ("fwd", "fwd_pw")}
     if which != "all":             # run (and warm up with) the selected entry only: a forward entry would rewrite Y, whose
