@@ -54,7 +54,7 @@ DOMINANT_KERNEL_HBM_BYTES = {"fp32": 2 * 324658 * 1024 + 304764 * 1024, "fp32_sp
 
 # the same for the eval-mode hidden Linear (relu + affine epilogue) in the two-piece mode at the shapes the scoring and
 # imputation legs run by default: {rows M: bytes} (profiles/r2b_gemm_two_piece_pmc.md)
-EVAL_KERNEL_HBM_BYTES = {819200: 2 * 4989340 * 1024 + 3533180 * 1024, 25000: 2 * 151129 * 1024 + 106064 * 1024}
+EVAL_KERNEL_HBM_BYTES = {819200: 2 * 4987133 * 1024 + 3456003 * 1024, 25000: 2 * 151171 * 1024 + 105498 * 1024}
 
 
 KERNEL_NAME = {"fp32_split": "gemm_split_mfma", "fp32_split2": "gemm_split_mfma", "fp32": "gemm_f32_mfma", "bf16": "gemm_bf16_mfma"}

@@ -65,6 +65,24 @@ def test_linear_relu_stats(dev, gemm_mode, M, K, N):
     close(rv, 0.9 + 0.1 * yr.var(0, unbiased=True), 2e-5, 0, "running_var")
 
 
+@pytest.mark.parametrize("M,K,N,ldx,ldr,ldo", [(300, 1000, 1000, 1024, 1024, 1024), (130, 52, 100, 52, 128, 104), (257, 40, 24, 64, 24, 32)])
+def test_linear_relu_affine_with_row_pitches(dev, gemm_mode, M, K, N, ldx, ldr, ldo):
+    """``btvae_linear_relu_affine_fwd_pw_ld``: activation, residual and output in buffers with row pitches of their own give
+    the bits of the dense call, leave the padding alone, and a pitch below N is refused."""
+    X, W, b = rnd(M, K, seed=1).float().to(dev), rnd(N, K, seed=2, scale=0.3).float().to(dev), rnd(N, seed=3).float().to(dev)
+    sc, sh, R = rnd(N, seed=4).float().to(dev), rnd(N, seed=5).float().to(dev), rnd(M, N, seed=6).float().to(dev)
+    dense = torch.empty(M, N, device=dev)
+    nv.call("btvae_linear_relu_affine_fwd_pw", P(X), K, P(W), None, P(b), P(sc), P(sh), P(R), P(dense), M, K, N)
+    Xp, Rp = torch.full((M, ldx), 7.0, device=dev), torch.full((M, ldr), 7.0, device=dev)
+    Xp[:, :K], Rp[:, :N] = X, R
+    Op = torch.full((M, ldo), -3.0, device=dev)
+    nv.call("btvae_linear_relu_affine_fwd_pw_ld", P(Xp), ldx, P(W), None, P(b), P(sc), P(sh), P(Rp), ldr, P(Op), ldo, M, K, N)
+    assert torch.equal(Op[:, :N], dense)
+    assert bool((Op[:, N:] == -3.0).all())
+    with pytest.raises(RuntimeError, match="row pitch"):
+        nv.call("btvae_linear_relu_affine_fwd_pw_ld", P(Xp), ldx, P(W), None, P(b), P(sc), P(sh), P(Rp), ldr, P(Op), N - 4, M, K, N)
+
+
 @pytest.mark.parametrize("M,K,N", [(200, 96, 100), (300, 1000, 48), (130, 52, 24), (257, 40, 10), (64, 1000, 64)])
 def test_linear_relu_affine_and_head(dev, gemm_mode, M, K, N):
     """N <= 64 takes the narrow head kernel in the split mode (N=10: its scalar-store path), N=100 the 128-wide tile."""
