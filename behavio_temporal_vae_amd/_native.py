@@ -100,6 +100,7 @@ _RET = {
     "btvae_prof_enabled": (c_int, []),
     "btvae_gemm_operand_maxima": (c_int, [P, P]),
     "btvae_output_maximum": (c_int, [P]),
+    "btvae_next_row_pitches": (c_int, [I, I]),
 }
 EXPORTS = sorted(list(_SIGS) + list(_RET))
 PROF_KINDS = ["gemm_fwd", "gemm_dgrad", "gemm_wgrad", "gemm_mvn", "bn", "mvn_rows", "reduce", "optim"]
@@ -188,6 +189,7 @@ def call(name: str, *args):
         # a request meant for the launch that did not happen must not reach a later one
         lib().btvae_gemm_operand_maxima(None, None)
         lib().btvae_output_maximum(None)
+        lib().btvae_next_row_pitches(0, 0)
         raise RuntimeError(f"{name}: {msg}")
 
 

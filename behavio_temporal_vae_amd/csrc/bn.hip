@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ R,
                                                            const unsigned char* __restrict__ keep, float keep_scale,
-                                                           float* __restrict__ Out, int M, int N, int rows_per_chunk,
+                                                           float* __restrict__ Out, int M, int N, int ld, int rows_per_chunk,
                                                            float* __restrict__ amax_out) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + lane) * VEC;
@@ -163,12 +163,12 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
     const int r0 = blockIdx.y * rows_per_chunk, r1 = ok ? min(M, r0 + rows_per_chunk) : 0;
 #pragma unroll 4
     for (int r = r0 + w; r < r1; r += 4) {
-        const size_t o = (size_t)r * N + col;
+        const size_t o = (size_t)r * ld + col, ok_ = (size_t)r * N + col;     // rows ld floats apart; keep flags dense
         if (VEC == 4) {
             float4 y = *reinterpret_cast<const float4*>(Y + o);
             float4 v = make_float4(y.x * sc[0] + sh[0], y.y * sc[1] + sh[1], y.z * sc[2] + sh[2], y.w * sc[3] + sh[3]);
             if (keep) {
-                const uchar4 k = *reinterpret_cast<const uchar4*>(keep + o);
+                const uchar4 k = *reinterpret_cast<const uchar4*>(keep + ok_);
                 v.x = k.x ? v.x * keep_scale : 0.f; v.y = k.y ? v.y * keep_scale : 0.f;
                 v.z = k.z ? v.z * keep_scale : 0.f; v.w = k.w ? v.w * keep_scale : 0.f;
             }
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
             vmax = amax4(vmax, v);
         } else {
             float v = Y[o] * sc[0] + sh[0];
-            if (keep) v = keep[o] ? v * keep_scale : 0.f;
+            if (keep) v = keep[ok_] ? v * keep_scale : 0.f;
             if (R) v += R[o];
             Out[o] = v;
             vmax = fmaxf(vmax, fabsf(v));
@@ -191,7 +191,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ G, const float* __restrict__ Y,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const unsigned char* __restrict__ keep, float keep_scale,
-                                                            float* __restrict__ partials, int M, int N, int rows_per_chunk) {
+                                                            float* __restrict__ partials, int M, int N, int ld, int rows_per_chunk) {
     __shared__ float red[4][64][2 * VEC];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + lane) * VEC;
@@ -203,12 +203,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     if (ok) {
 #pragma unroll 4
         for (int r = r0 + w; r < r1; r += 4) {
-            const size_t o = (size_t)r * N + col;
+            const size_t o = (size_t)r * ld + col, ok_ = (size_t)r * N + col;     // rows ld floats apart; keep flags dense
             if (VEC == 4) {
                 float4 g = *reinterpret_cast<const float4*>(G + o);
                 const float4 y = *reinterpret_cast<const float4*>(Y + o);
                 if (keep) {
-                    const uchar4 k = *reinterpret_cast<const uchar4*>(keep + o);
+                    const uchar4 k = *reinterpret_cast<const uchar4*>(keep + ok_);
                     g.x = k.x ? g.x * keep_scale : 0.f; g.y = k.y ? g.y * keep_scale : 0.f;
                     g.z = k.z ? g.z * keep_scale : 0.f; g.w = k.w ? g.w * keep_scale : 0.f;
                 }
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             } else {
                 float g = G[o];
                 const float y = Y[o];
-                if (keep) g = keep[o] ? g * keep_scale : 0.f;
+                if (keep) g = keep[ok_] ? g * keep_scale : 0.f;
                 s1[0] += g; s2[0] += g * ((y - mu[0]) * is[0]);
             }
         }
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ dbeta,
                                                            const unsigned char* __restrict__ keep, float keep_scale,
                                                            float* __restrict__ dPre,
-                                                           float* __restrict__ db_partials, int M, int N, int rows_per_chunk,
+                                                           float* __restrict__ db_partials, int M, int N, int ld, int rows_per_chunk,
                                                            float invM,            // 1 / rows the statistics were taken over
                                                            float* __restrict__ amax_out) {
     __shared__ float red[4][64][VEC];
@@ -317,12 +317,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     if (ok) {
 #pragma unroll 4
         for (int r = r0 + w; r < r1; r += 4) {
-            const size_t o = (size_t)r * N + col;
+            const size_t o = (size_t)r * ld + col, ok_ = (size_t)r * N + col;     // rows ld floats apart; keep flags dense
             if (VEC == 4) {
                 float4 g = *reinterpret_cast<const float4*>(G + o);
                 const float4 y = *reinterpret_cast<const float4*>(Y + o);
                 if (keep) {
-                    const uchar4 k = *reinterpret_cast<const uchar4*>(keep + o);
+                    const uchar4 k = *reinterpret_cast<const uchar4*>(keep + ok_);
                     g.x = k.x ? g.x * keep_scale : 0.f; g.y = k.y ? g.y * keep_scale : 0.f;
                     g.z = k.z ? g.z * keep_scale : 0.f; g.w = k.w ? g.w * keep_scale : 0.f;
                 }
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             } else {
                 float g = G[o];
                 const float y = Y[o];
-                if (keep) g = keep[o] ? g * keep_scale : 0.f;
+                if (keep) g = keep[ok_] ? g * keep_scale : 0.f;
                 const float d = y > 0.f ? k0[0] * g - k1[0] - k2[0] * ((y - mu[0]) * is[0]) : 0.f;
                 dPre[o] = d;
                 vmax = fmaxf(vmax, fabsf(d));
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // column sums of a plain [M,N] matrix (bias gradient of layers without ReLU/BN)
 template <int VEC>
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ G, float* __restrict__ partials, int M, int N, int rows_per_chunk) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ G, float* __restrict__ partials, int M, int N, int ld, int rows_per_chunk) {
     __shared__ float red[4][64][VEC];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + lane) * VEC;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ G
     const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
     if (ok) {
         for (int r = r0 + w; r < r1; r += 4) {
-            const size_t o = (size_t)r * N + col;
+            const size_t o = (size_t)r * ld + col;
             if (VEC == 4) { const float4 g = *reinterpret_cast<const float4*>(G + o); s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w; }
             else s[0] += G[o];
         }
@@ -399,10 +399,15 @@ __global__ __launch_bounds__(256) void dropout_keep_kernel(unsigned char* __rest
     else for (int j = 0; i0 + j < n; ++j) keep[i0 + j] = k[j];
 }
 
-inline bool vec4_ok(int N, const void* a, const void* b, const void* c, const void* d) {
+inline bool vec4_ok(int N, int ld, const void* a, const void* b, const void* c, const void* d) {
     auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    return N % 4 == 0 && al(a) && al(b) && al(c) && al(d);
+    return N % 4 == 0 && ld % 4 == 0 && al(a) && al(b) && al(c) && al(d);
 }
+
+// row pitch of this call's [M, N] matrices: the caller's request (btvae_next_row_pitches) or dense
+#define BTVAE_TAKE_LD(what) \
+    const int ld = [&] { const RowPitches rp = take_row_pitches(); return rp.n ? rp.n : N; }(); \
+    BTVAE_REQUIRE(ld >= N, what ": row pitch %d below N = %d", ld, N)
 
 inline int chunk_count(int M) { return std::max(1, std::min(256, (M + 63) / 64)); }
 
@@ -494,15 +499,16 @@ BTVAE_API int btvae_bn_fold_linear(const float* W, const float* b, const float* 
 BTVAE_API int btvae_bn_apply_fwd(const float* Y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                  const float* R, const unsigned char* keep, float keep_scale, float* Out, int M, int N,
                                  void* stream) {
+    BTVAE_TAKE_LD("bn_apply_fwd");
     float* amax_out = take_output_maximum();
     BTVAE_REQUIRE(Y && Out, "bn_apply_fwd: null pointer");
     BTVAE_REQUIRE(mean ? (invstd && gamma && beta) : (!invstd && !gamma && !beta), "bn_apply_fwd: pass all four BatchNorm vectors or none");
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
     ProfScope ps(PK_BN, (hipStream_t)stream, 0, 4.0 * M * N * (R ? 3 : 2) + (keep ? 1.0 * M * N : 0.0));
-    if (vec4_ok(N, Y, R, Out, keep))
-        hipLaunchKernelGGL((bn_apply_fwd_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, keep, keep_scale, Out, M, N, rpc, amax_out);
+    if (vec4_ok(N, ld, Y, R, Out, keep))
+        hipLaunchKernelGGL((bn_apply_fwd_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, keep, keep_scale, Out, M, N, ld, rpc, amax_out);
     else
-        hipLaunchKernelGGL((bn_apply_fwd_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, keep, keep_scale, Out, M, N, rpc, amax_out);
+        hipLaunchKernelGGL((bn_apply_fwd_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, keep, keep_scale, Out, M, N, ld, rpc, amax_out);
     return check_launch("bn_apply_fwd");
 }
 
@@ -514,22 +520,23 @@ BTVAE_API int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mea
                                 const unsigned char* keep, float keep_scale,
                                 float* dgamma, float* dbeta, float* dbias, float* dbias_cur, float* dPre, float* scratch, int M, int N,
                                 int accumulate, void* stream) {
+    BTVAE_TAKE_LD("bn_relu_bwd");
     float* amax_out = take_output_maximum();
     BTVAE_REQUIRE(G && Y && mean && invstd && gamma && dgamma && dbeta && dbias && dPre && scratch, "bn_relu_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
     float* p2 = scratch;                          // [chunks][2][N]
     float* p1 = scratch + (size_t)2 * chunks * N;   // [chunks][N]
-    const bool v4 = vec4_ok(N, G, Y, dPre, keep);
+    const bool v4 = vec4_ok(N, ld, G, Y, dPre, keep);
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 5 + (keep ? 2.0 * M * N : 0.0));
-    if (v4) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, p2, M, N, rpc);
-    else    hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, p2, M, N, rpc);
+    if (v4) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, p2, M, N, ld, rpc);
+    else    hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, p2, M, N, ld, rpc);
     // k=0 -> sum g (dbeta), k=1 -> sum g*xhat (dgamma); current-batch values go to the tail of the scratch
     float* cur_dbeta = scratch + (size_t)3 * chunks * N;
     float* cur_dgamma = cur_dbeta + N;
     colsum_finalize(s, p2, chunks, 2, N, dbeta, dgamma, cur_dbeta, cur_dgamma, accumulate);
-    if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc, 1.f / (float)M, amax_out);
-    else    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, rpc, 1.f / (float)M, amax_out);
+    if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, ld, rpc, 1.f / (float)M, amax_out);
+    else    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, ld, rpc, 1.f / (float)M, amax_out);
     colsum_finalize(s, p1, chunks, 1, N, dbias, (float*)nullptr, dbias_cur, (float*)nullptr, accumulate);
     return check_launch("bn_relu_bwd");
 }
@@ -551,12 +558,13 @@ BTVAE_API int btvae_dropout_keep_mask(unsigned char* keep, long long n, float p,
 BTVAE_API int btvae_bn_relu_bwd_sums(const float* G, const float* Y, const float* mean, const float* invstd,
                                      const unsigned char* keep, float keep_scale, float* dgamma, float* dbeta, float* sums,
                                      float* scratch, int M, int N, int accumulate, void* stream) {
+    BTVAE_TAKE_LD("bn_relu_bwd_sums");
     BTVAE_REQUIRE(G && Y && mean && invstd && dgamma && dbeta && sums && scratch, "bn_relu_bwd_sums: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 2 + (keep ? 1.0 * M * N : 0.0));
-    if (vec4_ok(N, G, Y, nullptr, keep)) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, scratch, M, N, rpc);
-    else                                 hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, scratch, M, N, rpc);
+    if (vec4_ok(N, ld, G, Y, nullptr, keep)) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, scratch, M, N, ld, rpc);
+    else                                 hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, scratch, M, N, ld, rpc);
     colsum_finalize(s, scratch, chunks, 2, N, dbeta, dgamma, sums, sums + N, accumulate);
     return check_launch("bn_relu_bwd_sums");
 }
@@ -576,6 +584,7 @@ BTVAE_API int btvae_bn_bwd_sums_from_products(const float* col_wp, const float* 
 BTVAE_API int btvae_bn_relu_bwd_apply(const float* G, const float* Y, const float* mean, const float* invstd, const float* gamma,
                                       const unsigned char* keep, float keep_scale, const float* sums, long long total_rows,
                                       float* dbias, float* dbias_cur, float* dPre, float* scratch, int M, int N, int accumulate, void* stream) {
+    BTVAE_TAKE_LD("bn_relu_bwd_apply");
     float* amax_out = take_output_maximum();
     BTVAE_REQUIRE(G && Y && mean && invstd && gamma && sums && dbias && dPre && scratch, "bn_relu_bwd_apply: null pointer");
     BTVAE_REQUIRE(total_rows >= M, "bn_relu_bwd_apply: total_rows %lld < local rows %d", total_rows, M);
@@ -583,10 +592,10 @@ BTVAE_API int btvae_bn_relu_bwd_apply(const float* G, const float* Y, const floa
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
     const float inv = 1.f / (float)total_rows;
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 3 + (keep ? 1.0 * M * N : 0.0));
-    if (vec4_ok(N, G, Y, dPre, keep))
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, rpc, inv, amax_out);
+    if (vec4_ok(N, ld, G, Y, dPre, keep))
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, ld, rpc, inv, amax_out);
     else
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, rpc, inv, amax_out);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, ld, rpc, inv, amax_out);
     colsum_finalize(s, scratch, chunks, 1, N, dbias, (float*)nullptr, dbias_cur, (float*)nullptr, accumulate);
     return check_launch("bn_relu_bwd_apply");
 }
@@ -595,16 +604,17 @@ BTVAE_API int btvae_bn_relu_bwd_apply(const float* G, const float* Y, const floa
 // scratch: btvae_strip_chunks(M) * N floats.
 BTVAE_API int btvae_relu_bwd(const float* G, const float* Y, const unsigned char* keep, float keep_scale, float* dbias,
                              float* dbias_cur, float* dPre, float* scratch, int M, int N, int accumulate, void* stream) {
+    BTVAE_TAKE_LD("relu_bwd");
     float* amax_out = take_output_maximum();
     BTVAE_REQUIRE(G && Y && dbias && dPre && scratch, "relu_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
     const float* none = nullptr;
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 3 + (keep ? 1.0 * M * N : 0.0));
-    if (vec4_ok(N, G, Y, dPre, keep))
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc, 1.f, amax_out);
+    if (vec4_ok(N, ld, G, Y, dPre, keep))
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, ld, rpc, 1.f, amax_out);
     else
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, rpc, 1.f, amax_out);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, ld, rpc, 1.f, amax_out);
     colsum_finalize(s, scratch, chunks, 1, N, dbias, (float*)nullptr, dbias_cur, (float*)nullptr, accumulate);
     return check_launch("relu_bwd");
 }
@@ -632,14 +642,15 @@ BTVAE_API long long btvae_bn_relu_bwd_scratch(int M, int N) { return (long long)
 // out[N] (+)= column sums of G[M,N], cur[N] = the sums alone (either may be null); scratch needs
 // btvae_strip_chunks(M) * N floats.
 BTVAE_API int btvae_colsum(const float* G, float* out, float* cur, float* scratch, int M, int N, int accumulate, void* stream) {
+    BTVAE_TAKE_LD("colsum");
     BTVAE_REQUIRE(G && (out || cur) && scratch, "colsum: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N);
-    if (vec4_ok(N, G, nullptr, nullptr, nullptr))
-        hipLaunchKernelGGL((colsum_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, scratch, M, N, rpc);
+    if (vec4_ok(N, ld, G, nullptr, nullptr, nullptr))
+        hipLaunchKernelGGL((colsum_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, scratch, M, N, ld, rpc);
     else
-        hipLaunchKernelGGL((colsum_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, scratch, M, N, rpc);
+        hipLaunchKernelGGL((colsum_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, scratch, M, N, ld, rpc);
     colsum_finalize(s, scratch, chunks, 1, N, out, (float*)nullptr, cur, (float*)nullptr, accumulate);
     return check_launch("colsum");
 }
@@ -691,10 +702,10 @@ BTVAE_API int btvae_colsum_noalloc(const float* G, float* out, float* cur, int M
     BTVAE_REQUIRE(ptr != nullptr, "colsum_noalloc: btvae_init(%d) has not run on the current device", dev);
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N);
-    if (vec4_ok(N, G, nullptr, nullptr, nullptr))
-        hipLaunchKernelGGL((colsum_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, ptr, M, N, rpc);
+    if (vec4_ok(N, N, G, nullptr, nullptr, nullptr))
+        hipLaunchKernelGGL((colsum_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, ptr, M, N, N, rpc);
     else
-        hipLaunchKernelGGL((colsum_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, ptr, M, N, rpc);
+        hipLaunchKernelGGL((colsum_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, ptr, M, N, N, rpc);
     colsum_finalize(s, ptr, chunks, 1, N, out, (float*)nullptr, cur, (float*)nullptr, accumulate);
     return check_launch("colsum_noalloc");
 }

@@ -37,6 +37,11 @@ struct ProfScope {
 // returns it and clears the request.
 float* take_output_maximum();
 
+// Row pitches (in floats; 0 = dense) that the next launch from this thread applies to its activation / gradient matrices
+// with N and with K columns (btvae_next_row_pitches); the call returns them and clears the request.
+struct RowPitches { int n, k; };
+RowPitches take_row_pitches();
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error("%s: launch failed: %s", what, hipGetErrorString(e));

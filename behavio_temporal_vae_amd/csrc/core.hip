@@ -63,6 +63,9 @@ void prof_end(int kind, hipStream_t s) {
 static thread_local float* t_out_max = nullptr;
 float* take_output_maximum() { float* p = t_out_max; t_out_max = nullptr; return p; }
 
+static thread_local RowPitches t_pitches = {0, 0};
+RowPitches take_row_pitches() { const RowPitches p = t_pitches; t_pitches = RowPitches{0, 0}; return p; }
+
 int noalloc_scratch_setup(int device);     // bn.hip: device address of the static scratch array on the current device
 
 }  // namespace btvae
@@ -100,6 +103,19 @@ BTVAE_API int btvae_init(int device) {
 // scalar *amax_out, which must hold zero or a maximum to
 // extend.  Any other entry point of the families above clears the request unused.
 BTVAE_API int btvae_output_maximum(float* amax_out) { t_out_max = amax_out; return 0; }
+
+// Activation and gradient matrices with a row pitch: the next launch, from the calling thread, of one of
+// btvae_linear_relu_stats_fwd* (Y), btvae_bn_apply_fwd (Y, R, Out), btvae_linear_dgrad* / _bnbwd* / _gstats* (dY; and R,
+// Yb, dPre / dX for the two fused forms), btvae_linear_wgrad / _affine (dY), btvae_bn_relu_bwd / _sums / _apply and
+// btvae_relu_bwd (G, Y, dPre), btvae_colsum (G) reads and writes those [M, N] matrices with rows ld_n floats apart and
+// the [M, K] ones ld_k apart (0 = dense; each must be at least the matrix's width; operands that already have a leading-
+// dimension argument keep it; dropout keep flags stay dense).  Rows that start on 128-byte lines are read by the products
+// in whole sectors.  Consumed by that launch.
+BTVAE_API int btvae_next_row_pitches(int ld_n, int ld_k) {
+    BTVAE_REQUIRE(ld_n >= 0 && ld_k >= 0, "next_row_pitches: negative pitch");
+    t_pitches = RowPitches{ld_n, ld_k};
+    return 0;
+}
 
 // Turn event timing of kernel families on/off; turning it on clears earlier records.
 BTVAE_API int btvae_prof_enable(int on) {

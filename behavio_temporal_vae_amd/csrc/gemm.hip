@@ -693,13 +693,18 @@ inline void set_planes(GemmArgs& a, const void* planes, int N, int K, bool dx) {
     a.Bp = (const unsigned short*)planes + (dx ? planes_f_elems(N, K) : 0);
     a.bp_tiles = dx ? (N + 15) / 16 : (K + 15) / 16;
 }
+// pitch of a matrix with `width` columns under the caller's request (0 = dense); false when the request is too small
+inline bool pitch_of(int requested, int width, int& ld) { ld = requested ? requested : width; return ld >= width; }
 }  // namespace
 
 // Y = relu(X W^T + b), plus per-128-row-tile column (mean, M2) partials for BatchNorm statistics.
 BTVAE_API int btvae_linear_relu_stats_fwd_pw(const float* X, int ldx, const float* W, const void* Wplanes, const float* b, float* Y,
                                              float* stat_partials, int M, int K, int N, void* stream) {
+    const RowPitches rp = take_row_pitches();
+    int ldy;
+    BTVAE_REQUIRE(pitch_of(rp.n, N, ldy), "linear_relu_stats_fwd: row pitch %d below N = %d", rp.n, N);
     BTVAE_REQUIRE(b && stat_partials, "linear_relu_stats_fwd: null bias/stats");
-    GemmArgs a{}; a.A = X; a.lda = ldx; a.B = W; a.ldb = K; a.C = Y; a.ldc = N; a.M = M; a.N = N; a.K = K;
+    GemmArgs a{}; a.A = X; a.lda = ldx; a.B = W; a.ldb = K; a.C = Y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
     a.bias = b; a.stats = stat_partials; set_planes(a, Wplanes, N, K, false);
     ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     return launch<LAY_K, LAY_K, EPI_RELU_STATS>(a, 1, (hipStream_t)stream, "linear_relu_stats_fwd", true);
@@ -789,7 +794,10 @@ BTVAE_API int btvae_linear_head_fwd_ws(const float* X, int ldx, const float* W, 
 
 // dX[M,K] = dY[M,N] W[N,K] (+ R[M,K]).
 BTVAE_API int btvae_linear_dgrad_pw(const float* dY, const float* W, const void* Wplanes, const float* R, float* dX, int lddx, int M, int N, int K, void* stream) {
-    GemmArgs a{}; a.A = dY; a.lda = N; a.B = W; a.ldb = K; a.C = dX; a.ldc = lddx; a.M = M; a.N = K; a.K = N;
+    const RowPitches rp = take_row_pitches();
+    int lddy;
+    BTVAE_REQUIRE(pitch_of(rp.n, N, lddy), "linear_dgrad: row pitch %d below N = %d", rp.n, N);
+    GemmArgs a{}; a.A = dY; a.lda = lddy; a.B = W; a.ldb = K; a.C = dX; a.ldc = lddx; a.M = M; a.N = K; a.K = N;
     a.R = R; a.ldr = lddx; set_planes(a, Wplanes, N, K, true);
     ProfScope ps(PK_GEMM_DGRAD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * N + (double)N * K + (double)M * K));
     return launch<LAY_K, LAY_M, EPI_PLAIN>(a, 1, (hipStream_t)stream, "linear_dgrad", true);
@@ -806,11 +814,14 @@ BTVAE_API int btvae_linear_dgrad(const float* dY, const float* W, const float* R
 BTVAE_API int btvae_linear_dgrad_bnbwd_pw(const float* dY, const float* W, const void* Wplanes, const float* R, const float* Yb, const float* mean,
                                           const float* invstd, const float* gamma, const float* sums, long long total_rows,
                                           float* dPre, float* colpart, int M, int N, int K, void* stream) {
+    const RowPitches rp = take_row_pitches();
+    int lddy, ldk;
+    BTVAE_REQUIRE(pitch_of(rp.n, N, lddy) && pitch_of(rp.k, K, ldk) && ldk % 4 == 0, "linear_dgrad_bnbwd: row pitches (%d, %d) below N = %d / K = %d or K-side pitch not a multiple of 4", rp.n, rp.k, N, K);
     BTVAE_REQUIRE(Yb && mean && invstd && gamma && sums && dPre && colpart, "linear_dgrad_bnbwd: null pointer");
     BTVAE_REQUIRE(total_rows >= M, "linear_dgrad_bnbwd: total_rows %lld < local rows %d", total_rows, M);
     BTVAE_REQUIRE(K % 4 == 0 && aligned16(dPre) && aligned16(Yb) && (!R || aligned16(R)), "linear_dgrad_bnbwd: needs K %% 4 == 0 and 16-byte aligned tensors");
-    GemmArgs a{}; a.A = dY; a.lda = N; a.B = W; a.ldb = K; a.C = dPre; a.ldc = K; a.M = M; a.N = K; a.K = N;
-    a.R = R; a.ldr = K;
+    GemmArgs a{}; a.A = dY; a.lda = lddy; a.B = W; a.ldb = K; a.C = dPre; a.ldc = ldk; a.M = M; a.N = K; a.K = N;
+    a.R = R; a.ldr = ldk;
     a.bn_y = Yb; a.bn_mean = mean; a.bn_invstd = invstd; a.bn_gamma = gamma; a.bn_sums = sums; a.bn_inv_rows = 1.f / (float)total_rows;
     a.colpart = colpart; set_planes(a, Wplanes, N, K, true);
     ProfScope ps(PK_GEMM_DGRAD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * N + (double)N * K + 2.0 * M * K));
@@ -827,10 +838,13 @@ BTVAE_API int btvae_linear_dgrad_bnbwd(const float* dY, const float* W, const fl
 // xhat = (Yb - mean) * invstd (finished by btvae_bn_bwd_sums_from_partials).  K % 4 == 0, 16-byte aligned tensors.
 BTVAE_API int btvae_linear_dgrad_gstats_pw(const float* dY, const float* W, const void* Wplanes, const float* R, const float* Yb, const float* mean,
                                            const float* invstd, float* dX, float* gpart, int M, int N, int K, void* stream) {
+    const RowPitches rp = take_row_pitches();
+    int lddy, ldk;
+    BTVAE_REQUIRE(pitch_of(rp.n, N, lddy) && pitch_of(rp.k, K, ldk) && ldk % 4 == 0, "linear_dgrad_gstats: row pitches (%d, %d) below N = %d / K = %d or K-side pitch not a multiple of 4", rp.n, rp.k, N, K);
     BTVAE_REQUIRE(Yb && mean && invstd && dX && gpart, "linear_dgrad_gstats: null pointer");
     BTVAE_REQUIRE(K % 4 == 0 && aligned16(dX) && aligned16(Yb) && (!R || aligned16(R)), "linear_dgrad_gstats: needs K %% 4 == 0 and 16-byte aligned tensors");
-    GemmArgs a{}; a.A = dY; a.lda = N; a.B = W; a.ldb = K; a.C = dX; a.ldc = K; a.M = M; a.N = K; a.K = N;
-    a.R = R; a.ldr = K;
+    GemmArgs a{}; a.A = dY; a.lda = lddy; a.B = W; a.ldb = K; a.C = dX; a.ldc = ldk; a.M = M; a.N = K; a.K = N;
+    a.R = R; a.ldr = ldk;
     a.bn_y = Yb; a.bn_mean = mean; a.bn_invstd = invstd; a.gpart = gpart; set_planes(a, Wplanes, N, K, true);
     ProfScope ps(PK_GEMM_DGRAD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * N + (double)N * K + 2.0 * M * K));
     return launch<LAY_K, LAY_M, EPI_GSTATS>(a, 1, (hipStream_t)stream, "linear_dgrad_gstats", true);
@@ -891,7 +905,10 @@ BTVAE_API int btvae_matmul_tn(const float* A, int lda, const float* B, int ldb, 
 // dW[N,K] (+)= dY[M,N]^T X[M,K].
 BTVAE_API int btvae_linear_wgrad(const float* dY, const float* X, int ldx, float* dW, float* ws, long long ws_floats,
                                  int M, int N, int K, int accumulate, void* stream) {
-    return btvae_matmul_tn(dY, N, X, ldx, dW, ws, ws_floats, N, K, M, accumulate, PK_GEMM_WGRAD, stream);
+    const RowPitches rp = take_row_pitches();
+    int lddy;
+    BTVAE_REQUIRE(pitch_of(rp.n, N, lddy), "linear_wgrad: row pitch %d below N = %d", rp.n, N);
+    return btvae_matmul_tn(dY, lddy, X, ldx, dW, ws, ws_floats, N, K, M, accumulate, PK_GEMM_WGRAD, stream);
 }
 
 // Weight gradient of a Linear whose input is X = Y * scale + shift (column-wise, never materialised):
@@ -904,9 +921,12 @@ BTVAE_API int btvae_linear_wgrad_affine(const float* dY, const float* Y, int ldy
                                         const float* dbias_cur, const float* W, float* col_wp, float* col_wb, int cols_accumulate,
                                         float* dW, float* ws, long long ws_floats,
                                         int M, int N, int K, int accumulate, void* stream) {
+    const RowPitches rp = take_row_pitches();
+    int lddy;
+    BTVAE_REQUIRE(pitch_of(rp.n, N, lddy), "linear_wgrad_affine: row pitch %d below N = %d", rp.n, N);
     BTVAE_REQUIRE(scale && shift && dbias_cur, "linear_wgrad_affine: null scale / shift / dbias_cur");
     BTVAE_REQUIRE((W != nullptr) == (col_wp != nullptr) && (W != nullptr) == (col_wb != nullptr), "linear_wgrad_affine: pass W, col_wp and col_wb together or none");
-    return matmul_tn_impl(dY, N, Y, ldy, dW, ws, ws_floats, N, K, M, accumulate, PK_GEMM_WGRAD, (hipStream_t)stream, scale, shift, dbias_cur,
+    return matmul_tn_impl(dY, lddy, Y, ldy, dW, ws, ws_floats, N, K, M, accumulate, PK_GEMM_WGRAD, (hipStream_t)stream, scale, shift, dbias_cur,
                           W, col_wp, col_wb, cols_accumulate);
 }
 

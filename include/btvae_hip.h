@@ -126,6 +126,15 @@ int btvae_matmul_nt_add(const float* A, int lda, const float* B, int ldb, const 
 int btvae_matmul_nn_mul(const float* A, int lda, const float* B, int ldb, const float* E1, const float* E2, int lde,
                         float* C, int ldc, int M, int N, int K, void* stream);
 
+/* Activation and gradient matrices with a row pitch (no counterpart in the reference, whose tensors are dense).  The
+ * next launch, from the calling thread, of btvae_linear_relu_stats_fwd* (Y), btvae_bn_apply_fwd (Y, R, Out),
+ * btvae_linear_dgrad* (dY), btvae_linear_dgrad_bnbwd* / _gstats* (dY; R, Yb, dPre / dX), btvae_linear_wgrad / _affine (dY),
+ * btvae_bn_relu_bwd / _sums / _apply and btvae_relu_bwd (G, Y, dPre) or btvae_colsum (G) takes the rows of those [M, N]
+ * matrices to be ld_n floats apart and the rows of the [M, K] ones ld_k apart (0 = dense; at least the matrix's width;
+ * arguments that have a leading dimension of their own -- ldx, ldy, lddx -- keep it; dropout keep flags stay dense).
+ * Width-1000 rows that start on 128-byte lines (pitch 1024) make the products that read them 6-11 % faster. */
+int btvae_next_row_pitches(int ld_n, int ld_k);
+
 /* ---- BatchNorm1d (torch.nn.BatchNorm1d as used at src/submodels.py:20-21,50) ---- */
 int btvae_strip_chunks(int M);
 /* Merge the GEMM's per-tile partials: mean, invstd = 1/sqrt(biased var + eps); running buffers (may both be

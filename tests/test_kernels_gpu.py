@@ -65,6 +65,110 @@ def test_linear_relu_stats(dev, gemm_mode, M, K, N):
     close(rv, 0.9 + 0.1 * yr.var(0, unbiased=True), 2e-5, 0, "running_var")
 
 
+def test_row_pitches_match_dense(dev, gemm_mode):
+    """``btvae_next_row_pitches``: every entry point that honours it gives, on activation / gradient matrices kept in
+    buffers with padded rows, the bits it gives on dense ones; the padding of the outputs is not written; the request
+    is consumed by one launch; a pitch below the width is refused."""
+    M, N, K, LN, LK = 300, 200, 136, 224, 160
+    L = nv.lib()
+    f = lambda *shape, seed: rnd(*shape, seed=seed).float().to(dev)
+    X, W, b = f(M, K, seed=1), f(N, K, seed=2) * 0.3, f(N, seed=3)
+    dY, Rn, Rk = f(M, N, seed=4), f(M, N, seed=5), f(M, K, seed=6)
+    Yn, Yk = torch.relu(f(M, N, seed=7)), torch.relu(f(M, K, seed=8))
+    mean_n, inv_n, gam_n, bet_n = f(N, seed=9), f(N, seed=10).abs() + 0.5, f(N, seed=11), f(N, seed=12)
+    mean_k, inv_k, gam_k = f(K, seed=13), f(K, seed=14).abs() + 0.5, f(K, seed=15)
+    sums_n, sums_k = f(2, N, seed=16), f(2, K, seed=17)
+    keep = (torch.rand(M, N, generator=torch.Generator().manual_seed(18)) > 0.3).to(torch.uint8).to(dev)
+    sc_k, sh_k, dbc = f(K, seed=19), f(K, seed=20), f(N, seed=21)
+    tiles, chunks = (M + 127) // 128, L.btvae_strip_chunks(M)
+    ws = torch.empty(4 * 1024 * 1024, device=dev)
+
+    def run(pitched):
+        ln, lk = (LN, LK) if pitched else (N, K)
+
+        alive = []                         # a temporary handed to P() would be freed, and its block reused, before the launch
+
+        def buf(t, ld):                    # `t` in a buffer with rows `ld` apart, padding set to a sentinel
+            o = torch.full((t.shape[0], ld), 7.5, device=dev)
+            o[:, :t.shape[1]] = t
+            alive.append(o)
+            return o
+
+        def out(cols, ld):
+            return torch.full((M, ld), -3.25, device=dev)
+
+        def pitches(n=True, k=False):
+            if pitched:
+                L.btvae_next_row_pitches(ln if n else 0, lk if k else 0)
+
+        res = {}
+        Y, part = out(N, ln), torch.zeros(tiles, 2, N, device=dev)
+        pitches(); nv.call("btvae_linear_relu_stats_fwd_pw", P(X), K, P(W), None, P(b), P(Y), P(part), M, K, N)
+        res["relu_stats"] = (Y, N); res["relu_stats.part"] = (part, None)
+        O = out(N, ln)
+        pitches(); nv.call("btvae_bn_apply_fwd", P(buf(Yn, ln)), P(mean_n), P(inv_n), P(gam_n), P(bet_n), P(buf(Rn, ln)), P(keep), 1.25, P(O), M, N)
+        res["bn_apply"] = (O, N)
+        D = out(K, lk)
+        pitches(); nv.call("btvae_linear_dgrad_pw", P(buf(dY, ln)), P(W), None, P(buf(Rk, lk)), P(D), lk, M, N, K)
+        res["dgrad"] = (D, K)
+        D2, colpart = out(K, lk), torch.zeros(tiles, K, device=dev)
+        pitches(True, True)
+        nv.call("btvae_linear_dgrad_bnbwd_pw", P(buf(dY, ln)), P(W), None, P(buf(Rk, lk)), P(buf(Yk, lk)), P(mean_k), P(inv_k), P(gam_k), P(sums_k), M,
+                P(D2), P(colpart), M, N, K)
+        res["bnbwd"] = (D2, K); res["bnbwd.colpart"] = (colpart, None)
+        D3, gpart = out(K, lk), torch.zeros(tiles, 2, K, device=dev)
+        pitches(True, True)
+        nv.call("btvae_linear_dgrad_gstats_pw", P(buf(dY, ln)), P(W), None, P(buf(Rk, lk)), P(buf(Yk, lk)), P(mean_k), P(inv_k), P(D3), P(gpart), M, N, K)
+        res["gstats"] = (D3, K); res["gstats.gpart"] = (gpart, None)
+        dW = torch.zeros(N, K, device=dev)
+        pitches(); nv.call("btvae_linear_wgrad", P(buf(dY, ln)), P(buf(X, lk)), lk, P(dW), P(ws), ws.numel(), M, N, K, 0)
+        res["wgrad"] = (dW, None)
+        dW2, cwp, cwb = torch.zeros(N, K, device=dev), torch.zeros(K, device=dev), torch.zeros(K, device=dev)
+        pitches(); nv.call("btvae_linear_wgrad_affine", P(buf(dY, ln)), P(buf(Yk, lk)), lk, P(sc_k), P(sh_k), P(dbc), P(W), P(cwp), P(cwb), 0,
+                           P(dW2), P(ws), ws.numel(), M, N, K, 0)
+        res["wgrad_affine"] = (dW2, None); res["wgrad_affine.cols"] = (torch.stack([cwp, cwb]), None)
+        scratch = torch.zeros(L.btvae_bn_relu_bwd_scratch(M, N), device=dev)
+        dg, db, dbias, dcur = (torch.zeros(N, device=dev) for _ in range(4))
+        dP = out(N, ln)
+        pitches(); nv.call("btvae_bn_relu_bwd", P(buf(dY, ln)), P(buf(Yn, ln)), P(mean_n), P(inv_n), P(gam_n), P(keep), 1.25, P(dg), P(db), P(dbias), P(dcur),
+                           P(dP), P(scratch), M, N, 0)
+        res["bn_relu_bwd"] = (dP, N); res["bn_relu_bwd.vec"] = (torch.stack([dg, db, dbias, dcur]), None)
+        dg2, db2, sums = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros(2, N, device=dev)
+        pitches(); nv.call("btvae_bn_relu_bwd_sums", P(buf(dY, ln)), P(buf(Yn, ln)), P(mean_n), P(inv_n), P(keep), 1.25, P(dg2), P(db2), P(sums), P(scratch), M, N, 0)
+        res["bwd_sums"] = (torch.cat([sums, torch.stack([dg2, db2])]), None)
+        dbias3, dP3 = torch.zeros(N, device=dev), out(N, ln)
+        pitches(); nv.call("btvae_bn_relu_bwd_apply", P(buf(dY, ln)), P(buf(Yn, ln)), P(mean_n), P(inv_n), P(gam_n), P(keep), 1.25, P(sums_n), M, P(dbias3), None,
+                           P(dP3), P(scratch), M, N, 0)
+        res["bwd_apply"] = (dP3, N); res["bwd_apply.dbias"] = (dbias3, None)
+        dbias4, dP4 = torch.zeros(N, device=dev), out(N, ln)
+        pitches(); nv.call("btvae_relu_bwd", P(buf(dY, ln)), P(buf(Yn, ln)), P(keep), 1.25, P(dbias4), None, P(dP4), P(scratch), M, N, 0)
+        res["relu_bwd"] = (dP4, N); res["relu_bwd.dbias"] = (dbias4, None)
+        cs = torch.zeros(N, device=dev)
+        pitches(); nv.call("btvae_colsum", P(buf(dY, ln)), P(cs), None, P(scratch), M, N, 0)
+        res["colsum"] = (cs, None)
+        torch.cuda.synchronize()
+        return res
+
+    dense, pitched = run(False), run(True)
+    for name, (d, cols) in dense.items():
+        q = pitched[name][0]
+        if cols is None:
+            assert torch.equal(d, q), name
+        else:
+            assert torch.equal(d, q[:, :cols]), name
+            assert bool((q[:, cols:] == -3.25).all()), name + ": padding written"
+    # the request lasted one launch: a dense call right after a pitched one reads dense rows
+    L.btvae_next_row_pitches(LN, 0)
+    cs1, cs2, scratch = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros(chunks * N, device=dev)
+    big = torch.full((M, LN), 7.5, device=dev); big[:, :N] = dY
+    nv.call("btvae_colsum", P(big), P(cs1), None, P(scratch), M, N, 0)
+    nv.call("btvae_colsum", P(dY), P(cs2), None, P(scratch), M, N, 0)
+    assert torch.equal(cs1, cs2)
+    L.btvae_next_row_pitches(N - 4, 0)
+    with pytest.raises(RuntimeError, match="row pitch"):
+        nv.call("btvae_colsum", P(dY), P(cs2), None, P(scratch), M, N, 0)
+
+
 @pytest.mark.parametrize("M,K,N,ldx,ldr,ldo", [(300, 1000, 1000, 1024, 1024, 1024), (130, 52, 100, 52, 128, 104), (257, 40, 24, 64, 24, 32)])
 def test_linear_relu_affine_with_row_pitches(dev, gemm_mode, M, K, N, ldx, ldr, ldo):
     """``btvae_linear_relu_affine_fwd_pw_ld``: activation, residual and output in buffers with row pitches of their own give
