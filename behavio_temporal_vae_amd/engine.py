@@ -186,7 +186,7 @@ BWD_SUMS_IN_DGRAD = not os.environ.get('BTVAE_NO_DGRAD_SUMS')   # reduction pass
 BWD_FUSED_INTO_CONSUMER = not os.environ.get('BTVAE_NO_FUSED_BWD')   # ... and run their BatchNorm backward in the epilogue of the last such Linear's dX product
 
 
-PITCHED_EVAL = not os.environ.get('BTVAE_NO_PITCHED_EVAL')    # eval-mode activations in line-aligned rows (_rows_on_lines)
+PITCHED_ROWS = not os.environ.get('BTVAE_NO_PITCHED_ROWS')    # hidden activations and gradients in line-aligned rows (_rows_on_lines)
 PRESPLIT_WEIGHTS = not os.environ.get('BTVAE_NO_PRESPLIT')   # split mode: weights split into bf16 planes once per pass
 
 
@@ -327,16 +327,50 @@ def _plan_planes(plan: "NetPlan", backward: bool) -> Dict[torch.nn.Linear, torch
 ROW_LINE_FLOATS = 32       # a 128-byte line
 
 
-def _rows_on_lines(M: int, N: int, dev) -> torch.Tensor:
-    """An [M, N] activation buffer whose rows start on 128-byte lines (pitch = N rounded up to 32 floats; a view when
-    that pads).  The products read 64 bytes of each of 128 rows per step: from rows of 4000 bytes those pieces straddle
-    sectors and lines (-11 % on the N = K = 1000 product with line-aligned rows).  Only the eval-mode chain keeps its
-    activations this way: every kernel that touches them takes a row pitch (``btvae_linear_relu_affine_fwd_pw_ld``, the
-    head product's ``ldx``)."""
+def _rows_on_lines(M: int, N: int, dev, on: Optional[bool] = None) -> torch.Tensor:
+    """An [M, N] activation or gradient buffer whose rows start on 128-byte lines (pitch = N rounded up to 32 floats; a
+    view when that pads).  The products read 64 bytes of each of 128 rows per step: from rows of 4000 bytes those pieces
+    straddle sectors and lines (6 % of a product on real activations, 11 % at the full clock).  Every kernel that touches
+    such a matrix is told its pitch: a leading-dimension argument where the entry point has one, ``_pitches`` otherwise.
+    The pitch is a function of the width, so all [M, N] matrices of one call share it."""
     pitch = -(-N // ROW_LINE_FLOATS) * ROW_LINE_FLOATS
-    if pitch == N or not PITCHED_EVAL:
+    if pitch == N or not (PITCHED_ROWS if on is None else on):
         return torch.empty(M, N, device=dev)
     return torch.empty(M, pitch, device=dev)[:, :N]
+
+
+def _rows_like(ref: torch.Tensor) -> torch.Tensor:
+    """An uninitialised matrix of ``ref``'s shape and row pitch."""
+    M, N = ref.shape
+    if ref.stride(0) == N:
+        return torch.empty(M, N, device=ref.device)
+    return torch.empty(M, ref.stride(0), device=ref.device)[:, :N]
+
+
+def _pitches(n: Optional[torch.Tensor] = None, k: Optional[torch.Tensor] = None, same_n=(), same_k=()):
+    """Tell the next launch the row pitch of its [M, N] matrices (that of ``n``) and of its [M, K] ones (that of ``k``)
+    when either is padded (``btvae_next_row_pitches``).  ``same_n`` / ``same_k``: the call's other matrices of those
+    widths, which must have the same pitch (None entries are skipped)."""
+    ln = n.stride(0) if n is not None else 0
+    lk = k.stride(0) if k is not None else 0
+    for group, ld in ((same_n, ln), (same_k, lk)):
+        for t in group:
+            if t is not None and t.stride(0) != ld:
+                raise RuntimeError(f"matrices of one launch disagree on their row pitch: {tuple(t.shape)} has {t.stride(0)}, expected {ld}")
+    if (n is not None and ln != n.shape[1]) or (k is not None and lk != k.shape[1]):
+        nv.lib().btvae_next_row_pitches(ln, lk)
+
+
+def _like_rows(t: Optional[torch.Tensor], ref: torch.Tensor) -> Optional[torch.Tensor]:
+    """``t`` with the row pitch of ``ref`` (same shape): itself when it has it, else a copy (an input of the network that
+    a residual unit adds to a padded activation)."""
+    if t is None or t.stride(0) == ref.stride(0):
+        return t
+    out = _rows_like(ref)
+    out.copy_(t)
+    if getattr(t, "_btvae_amax", None) is not None:
+        out._btvae_amax = t._btvae_amax
+    return out
 
 
 def _linear_operands(lin: torch.nn.Linear, x):
@@ -386,11 +420,12 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
             # torch.nn.BatchNorm1d refuses a one-row batch in train mode (torch/nn/functional.py, _verify_batch_size)
             raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([{M}, {N}])")
         tiles = (M + 127) // 128
-        y = torch.empty(M, N, device=dev)
+        y = _rows_on_lines(M, N, dev)
         part = WS.get("bnpart", tiles * 2 * N, dev)
         _operand_maxima(_amax(x), _planes_amax(wp, W))
         _track_output(y)
-        nv.call("btvae_linear_relu_stats_fwd_pw", P(x), K, P(W), P(wp), P(b), P(y), P(part), M, K, N)
+        _pitches(n=y)
+        nv.call("btvae_linear_relu_stats_fwd_pw", PR(x), x.stride(0), P(W), P(wp), P(b), PR(y), P(part), M, K, N)
         mean, invstd = torch.empty(N, device=dev), torch.empty(N, device=dev)
         track = u.bn.track_running_stats and u.bn.running_mean is not None
         mom = u.bn.momentum if u.bn.momentum is not None else 0.1
@@ -416,25 +451,29 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
                 out_pr.owner = (u, saved[-1])
         if normed:
             return Normed(y, mean, invstd, u.bn.weight, u.bn.bias, out_pr)
-        out = torch.empty(M, N, device=dev)
+        out = _rows_on_lines(M, N, dev)
+        res_in = _like_rows(x, y) if u.residual else None
         _track_output(out)
-        nv.call("btvae_bn_apply_fwd", P(y), P(mean), P(invstd), P(u.bn.weight), P(u.bn.bias), P(x) if u.residual else None,
-                P(keep), ks, P(out), M, N)
+        _pitches(n=y, same_n=(res_in, out))
+        nv.call("btvae_bn_apply_fwd", PR(y), P(mean), P(invstd), P(u.bn.weight), P(u.bn.bias), PR(res_in),
+                P(keep), ks, PR(out), M, N)
         if saved is not None and keep is None:
             out._btvae_src = saved[-1]            # lets the Linear that reads `out` find this unit's record in the backward
     elif u.bn is None and train:
         # unit built without BatchNorm: y = relu(x W^T + b) is what the backward needs; dropout / residual on top
-        y = torch.empty(M, N, device=dev)
+        y = _rows_on_lines(M, N, dev)
         _operand_maxima(_amax(x), _planes_amax(wp, W))
         _track_output(y)
-        nv.call("btvae_linear_relu_affine_fwd_pw", P(x), K, P(W), P(wp), P(b), None, None, None, P(y), M, K, N)
+        nv.call("btvae_linear_relu_affine_fwd_pw_ld", PR(x), x.stride(0), P(W), P(wp), P(b), None, None, None, 0, PR(y), y.stride(0), M, K, N)
         keep, ks = None, 1.0
         if u.dropout_p > 0.0:
             keep, ks = DROPOUT.keep(M, N, u.dropout_p, dev), 1.0 / (1.0 - u.dropout_p)
         if keep is not None or u.residual:
-            out = torch.empty(M, N, device=dev)
+            out = _rows_on_lines(M, N, dev)
+            res_in = _like_rows(x, y) if u.residual else None
             _track_output(out)
-            nv.call("btvae_bn_apply_fwd", P(y), None, None, None, None, P(x) if u.residual else None, P(keep), ks, P(out), M, N)
+            _pitches(n=y, same_n=(res_in, out))
+            nv.call("btvae_bn_apply_fwd", PR(y), None, None, None, None, PR(res_in), P(keep), ks, PR(out), M, N)
         else:
             out = y
         if saved is not None:
@@ -539,14 +578,15 @@ def _wgrad(lin: torch.nn.Linear, dy: torch.Tensor, x: torch.Tensor, x_scale, x_s
     K = x.shape[1]
     ws = WS.get("wgrad", WGRAD_WS_FLOATS, dy.device)
     _operand_maxima(_amax(dy), _amax(x))
+    _pitches(n=dy)
     if x_scale is None:
-        nv.call("btvae_linear_wgrad", P(dy), P(x), K, P(_grad_view(lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
+        nv.call("btvae_linear_wgrad", PR(dy), PR(x), x.stride(0), P(_grad_view(lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
     elif products is not None and BWD_SUMS_FROM_CONSUMERS:
-        nv.call("btvae_linear_wgrad_affine", P(dy), P(x), K, P(x_scale), P(x_shift), P(db_cur), P(lin.weight), P(products.wp), P(products.wb),
+        nv.call("btvae_linear_wgrad_affine", PR(dy), PR(x), x.stride(0), P(x_scale), P(x_shift), P(db_cur), P(lin.weight), P(products.wp), P(products.wb),
                 int(products.filled > 0), P(_grad_view(lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
         products.filled += 1
     else:
-        nv.call("btvae_linear_wgrad_affine", P(dy), P(x), K, P(x_scale), P(x_shift), P(db_cur), None, None, None, 0,
+        nv.call("btvae_linear_wgrad_affine", PR(dy), PR(x), x.stride(0), P(x_scale), P(x_shift), P(db_cur), None, None, None, 0,
                 P(_grad_view(lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
 
 
@@ -573,12 +613,14 @@ def _dgrad_with_producer_backward(pr: BwdProducts, dy: torch.Tensor, W: torch.Te
     if sv_p.total_rows > M:
         BN_SYNC.sum_(sums)
     tiles = (M + 127) // 128
-    dpre = torch.empty(M, Np, device=dev)
+    dpre = _rows_like(sv_p.y)
     part = WS.get("bnbwd_part", tiles * Np, dev)
+    r = _like_rows(r, dpre)
     _operand_maxima(_amax(dy), _planes_amax(planes, W))
     _track_output(dpre)
-    nv.call("btvae_linear_dgrad_bnbwd_pw", P(dy), P(W), P(planes), P(r), P(sv_p.y), P(sv_p.mean), P(sv_p.invstd), P(u_p.bn.weight), P(sums),
-            int(max(sv_p.total_rows, M)), P(dpre), P(part), M, N, Np)
+    _pitches(n=dy, k=dpre, same_k=(r, sv_p.y))
+    nv.call("btvae_linear_dgrad_bnbwd_pw", PR(dy), P(W), P(planes), PR(r), PR(sv_p.y), P(sv_p.mean), P(sv_p.invstd), P(u_p.bn.weight), P(sums),
+            int(max(sv_p.total_rows, M)), PR(dpre), P(part), M, N, Np)
     db_cur = torch.empty(Np, device=dev) if sv_p.x_scale is not None else None
     nv.call("btvae_colsum_partials", P(part), tiles, Np, P(_grad_view(u_p.lin.bias)), P(db_cur), int(accumulate))
     pr.dpre, pr.db_cur = dpre, db_cur
@@ -599,13 +641,15 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
         dpre, db_cur, scr = pr.dpre, pr.db_cur, None
     else:
         scr = WS.get("bnbwd", nv.lib().btvae_bn_relu_bwd_scratch(M, N), dev)
-        dpre = torch.empty(M, N, device=dev)
+        dpre = _rows_like(sv.y)
+        g = _like_rows(g, sv.y)
         db_cur = torch.empty(N, device=dev) if sv.x_scale is not None else None    # this pass's bias gradient, for the affine wgrad
     if fused_done:
         pass
     elif u.bn is None:
         _track_output(dpre)
-        nv.call("btvae_relu_bwd", P(g), P(sv.y), P(sv.keep), float(sv.keep_scale), P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
+        _pitches(n=sv.y, same_n=(g, dpre))
+        nv.call("btvae_relu_bwd", PR(g), PR(sv.y), P(sv.keep), float(sv.keep_scale), P(_grad_view(u.lin.bias)), P(db_cur), PR(dpre), P(scr), M, N, int(accumulate))
     elif pr is not None and pr.consumers > 0 and pr.filled == pr.consumers and sv.keep is None:
         # every reader of this unit's output was a folded Linear whose weight gradient has run: the column sums of
         # G and G*xhat follow from their by-products, no reduction pass over G and Y
@@ -615,8 +659,9 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
         if sv.total_rows > M:
             BN_SYNC.sum_(sums)
         _track_output(dpre)
-        nv.call("btvae_bn_relu_bwd_apply", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), None, 1.0,
-                P(sums), int(max(sv.total_rows, M)), P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
+        _pitches(n=sv.y, same_n=(g, dpre))
+        nv.call("btvae_bn_relu_bwd_apply", PR(g), PR(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), None, 1.0,
+                P(sums), int(max(sv.total_rows, M)), P(_grad_view(u.lin.bias)), P(db_cur), PR(dpre), P(scr), M, N, int(accumulate))
     elif sv.g_partials is not None:
         # the dX product that formed g left the per-tile column sums of g and g*xhat: no reduction pass over g and y
         part, tiles = sv.g_partials
@@ -625,22 +670,26 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
         if sv.total_rows > M:
             BN_SYNC.sum_(sums)
         _track_output(dpre)
-        nv.call("btvae_bn_relu_bwd_apply", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), None, 1.0,
-                P(sums), int(max(sv.total_rows, M)), P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
+        _pitches(n=sv.y, same_n=(g, dpre))
+        nv.call("btvae_bn_relu_bwd_apply", PR(g), PR(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), None, 1.0,
+                P(sums), int(max(sv.total_rows, M)), P(_grad_view(u.lin.bias)), P(db_cur), PR(dpre), P(scr), M, N, int(accumulate))
     elif sv.total_rows > M:
         # statistics span ranks: local column sums -> sum over ranks -> dPre with the batch-wide sums
         sums = torch.empty(2, N, device=dev)
-        nv.call("btvae_bn_relu_bwd_sums", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(sv.keep), float(sv.keep_scale),
+        _pitches(n=sv.y, same_n=(g,))
+        nv.call("btvae_bn_relu_bwd_sums", PR(g), PR(sv.y), P(sv.mean), P(sv.invstd), P(sv.keep), float(sv.keep_scale),
                 P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)), P(sums), P(scr), M, N, int(accumulate))
         BN_SYNC.sum_(sums)
         _track_output(dpre)
-        nv.call("btvae_bn_relu_bwd_apply", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
-                P(sums), int(sv.total_rows), P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
+        _pitches(n=sv.y, same_n=(g, dpre))
+        nv.call("btvae_bn_relu_bwd_apply", PR(g), PR(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
+                P(sums), int(sv.total_rows), P(_grad_view(u.lin.bias)), P(db_cur), PR(dpre), P(scr), M, N, int(accumulate))
     else:
         _track_output(dpre)
-        nv.call("btvae_bn_relu_bwd", P(g), P(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
+        _pitches(n=sv.y, same_n=(g, dpre))
+        nv.call("btvae_bn_relu_bwd", PR(g), PR(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
                 P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)),
-                P(_grad_view(u.lin.bias)), P(db_cur), P(dpre), P(scr), M, N, int(accumulate))
+                P(_grad_view(u.lin.bias)), P(db_cur), PR(dpre), P(scr), M, N, int(accumulate))
     _wgrad(u.lin, dpre, sv.x_in, sv.x_scale, sv.x_shift, db_cur, accumulate, sv.x_products)
     if not need_dx:
         return None
@@ -653,7 +702,8 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
         r = add_to
     if _fusable(sv.x_products):
         return _dgrad_with_producer_backward(sv.x_products, dpre, u.lin.weight, r, accumulate, sv.w_planes)
-    dx = torch.empty(M, K, device=dev)
+    dx = _rows_like(sv.x_in)                  # a hidden activation's gradient has its pitch; the network input's is dense
+    r = _like_rows(r, dx)
     src = sv.x_src
     if src is not None:
         src.readers_done += 1
@@ -662,11 +712,13 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
         tiles = (M + 127) // 128
         part = torch.empty(tiles, 2, K, device=dev)
         _operand_maxima(_amax(dpre), _planes_amax(sv.w_planes, u.lin.weight))
-        nv.call("btvae_linear_dgrad_gstats_pw", P(dpre), P(u.lin.weight), P(sv.w_planes), P(r), P(src.y), P(src.mean), P(src.invstd), P(dx), P(part), M, N, K)
+        _pitches(n=dpre, k=dx, same_k=(r, src.y))
+        nv.call("btvae_linear_dgrad_gstats_pw", PR(dpre), P(u.lin.weight), P(sv.w_planes), PR(r), PR(src.y), P(src.mean), P(src.invstd), PR(dx), P(part), M, N, K)
         src.g_partials = (part, tiles)
     else:
         _operand_maxima(_amax(dpre), _planes_amax(sv.w_planes, u.lin.weight))
-        nv.call("btvae_linear_dgrad_pw", P(dpre), P(u.lin.weight), P(sv.w_planes), P(r), P(dx), K, M, N, K)
+        _pitches(n=dpre)
+        nv.call("btvae_linear_dgrad_pw", PR(dpre), P(u.lin.weight), P(sv.w_planes), PR(r), PR(dx), dx.stride(0), M, N, K)
     return dx
 
 
@@ -691,9 +743,9 @@ def net_backward(plan: NetPlan, tape: NetTape, draw: Dict[str, torch.Tensor], ne
         if _fusable(x_pr):
             g = _dgrad_with_producer_backward(x_pr, d, last.lin.weight, None, accumulate, tape.head_planes.get(name))
         else:
-            g = torch.empty(M, K, device=dev)
+            g = _rows_like(t_in)
             _operand_maxima(_amax(d), _planes_amax(tape.head_planes.get(name), last.lin.weight))
-            nv.call("btvae_linear_dgrad_pw", P(d), P(last.lin.weight), P(tape.head_planes.get(name)), None, P(g), K, M, N, K)
+            nv.call("btvae_linear_dgrad_pw", P(d), P(last.lin.weight), P(tape.head_planes.get(name)), None, PR(g), g.stride(0), M, N, K)
         svs = tape.heads[name]
         for i in range(len(units) - 2, -1, -1):
             first = i == 0
