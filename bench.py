@@ -49,7 +49,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X bf16 dense matrix peak (v_mfma_f32_32x
 SPLIT_TERMS = 6                  # bf16 MFMAs issued per fp32 product in the split mode
 # HBM-side bytes of one launch of the dominant kernel (M=65536, N=K=1000) from PMC passes kept under profiles/
 DOMINANT_KERNEL_HBM_BYTES = {"fp32": 2 * 324658 * 1024 + 304764 * 1024, "fp32_split": 2 * 505912 * 1024 + 258478 * 1024,
-                             "fp32_split2": 2 * 345092 * 1024 + 260049 * 1024}
+                             "fp32_split2": 2 * 387867 * 1024 + 292795 * 1024}       # inside the training leg, line-aligned rows
 
 
 # the same for the eval-mode hidden Linear (relu + affine epilogue) in the two-piece mode at the shapes the scoring and
@@ -632,6 +632,9 @@ def main():
                          "traffic": DOMINANT_KERNEL_HBM_BYTES.get(main_precision) if (S * B == 65536) else None,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this kernel at this shape, separate passes: profiles/r2b_gemm_two_piece_pmc.md (fp32_split2), profiles/r1_gemm_fwd_pmc.md (other modes); not collected live",
                          "algorithmic_bytes": 4.0 * (S * B * 1000 + 1000 * 1000 + S * B * 1000),
+                         "limiter_note": ("fp32_split2: with every MFMA removed this kernel takes 0.397 ms instead of 0.408 at the full clock: "
+                                          "its time is set by the global-memory path (activations re-read 8x and the weight image swept from L2, "
+                                          "512-byte output row pieces), profiles/r2b_gemm_two_piece_pmc.md") if main_precision == "fp32_split2" else None,
                          "fwd_family_tflops": fwd_fl / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else None,
                          "all_gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None,
                          "step_model_tflops": flops_per_sample(S) * B / (ms_step * 1e-3) / 1e12,
