@@ -203,12 +203,12 @@ GEMM_PRECISIONS = {"fp32": 0, "bf16": 1, "fp32_split": 2, "fp32_split2": 3}
 
 
 def set_gemm_precision(name: str):
-    """Operand precision of the Linear-layer products, process-wide: ``"fp32_split"`` (what models ask for unless
-    configured otherwise: fp32-accurate products as three-way bf16 splits on the bf16 matrix pipe), ``"fp32"`` (the fp32
-    MFMA instruction; the library's own start-up mode), ``"bf16"`` (bf16-rounded operands, fp32 accumulation) or
-    ``"fp32_split2"`` (as ``"fp32_split"``, but the Linear products whose callers supply their operands' absolute maxima
-    run on two fp16 pieces per value, scaled per tensor: three matrix instructions per product instead of six, element
-    errors ~2^-22 relative to the tensor's largest magnitude instead of to the element)."""
+    """Operand precision of the Linear-layer products, process-wide: ``"fp32_split2"`` (what models ask for unless
+    configured otherwise: the Linear products whose callers supply their operands' absolute maxima run on two fp16
+    pieces per value, scaled per tensor -- three matrix instructions per product, element errors ~2^-22 relative to the
+    tensor's largest magnitude; the others as ``"fp32_split"``), ``"fp32_split"`` (fp32-accurate products as exact
+    three-way bf16 splits on the bf16 matrix pipe, six matrix instructions), ``"fp32"`` (the fp32 MFMA instruction; the
+    library's own start-up mode) or ``"bf16"`` (bf16-rounded operands, fp32 accumulation)."""
     if name not in GEMM_PRECISIONS:
         raise ValueError(f"unknown GEMM precision {name!r}; choose from {sorted(GEMM_PRECISIONS)}")
     if lib().btvae_set_gemm_precision(GEMM_PRECISIONS[name]) != 0:

@@ -8,7 +8,7 @@ A step = one ``CVAE.train_core`` (forward, ELBO, backward, global-norm clip, Ada
 synthetic daily load profiles of the config0 shape (D=48, C=4, L=48, H=1000, V=100, S=16 MC samples,
 batch 4096 per GPU, fp32).  Inputs are generated on the device before the timed region.  Rank 0 prints one
 JSON line; ``value`` is whole-job samples/s.  Also reported: the roofline of the dominant kernel (the decoder's hidden
-Linear product, in the default mode fp32 operands as three-way bf16 splits on the bf16 matrix pipe) from HIP-event
+Linear product, in the default mode fp32 operands as two scaled fp16 pieces on the fp16 matrix pipe) from HIP-event
 timing on the launch stream inside the timed region; the same step at the other operand precisions; the K=1000
 importance-weighted scoring leg (``secondary``) and the pseudo-Gibbs imputation leg (``imputation``), each with the
 roofline of its own dominant kernel; an end-to-end run of ``scripts/training.main(config0)`` (``e2e``); the
