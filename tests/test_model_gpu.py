@@ -339,6 +339,52 @@ def test_wide_conditioning_3d_fp32_and_bf16(dev):
     nv.set_gemm_precision("fp32")
 
 
+@pytest.mark.parametrize("bn,dropout,prec", [(True, False, "fp32_split2"), (True, True, "fp32_split"), (False, True, "fp32_split2"), (False, False, "fp32")])
+def test_padded_activation_rows_change_no_bits(dev, monkeypatch, bn, dropout, prec):
+    """Hidden activations and gradients in rows padded to a multiple of 32 floats (``engine._rows_on_lines``; width 72 ->
+    pitch 96 here) against dense ones: the same kernels on the same values, so three training steps (losses, weights,
+    BatchNorm buffers) and an eval-mode forward agree to the last bit -- with and without BatchNorm, with dropout (whose
+    keep flags stay dense) and in every fp32-accurate GEMM mode."""
+    from behavio_temporal_vae_amd import engine as E
+    from behavio_temporal_vae_amd.vae_models import CVAE
+    H, D, C, B, S = 72, 24, 6, 200, 3
+    cfg = {"latent_dim": 10, "gemm_precision": prec, "distribution_dict": {
+        "posterior": {"dist_type": "normal", "sigma_lim": 0.05, "mu_upper_lim": 5.0, "mu_lower_lim": -5.0, "num_neurons": H,
+                      "num_hidden_layers": 2, "dropout": dropout, "dropout_rate": 0.2, "batch_normalization": bn},
+        "likelihood": {"dist_type": "dict-gauss", "vocab_size": 40, "sigma_lim": 1e-4, "marginal_std_lim": 0.1, "mu_lower_lim": -3,
+                       "num_neurons": H, "num_hidden_layers": 2, "dropout": dropout, "dropout_rate": 0.2, "batch_normalization": bn}}}
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B, D, generator=gen).clamp(-3, 5).to(dev)
+    c = torch.randn(B, C, generator=gen).to(dev)
+    eps = torch.randn(S, B, 10, generator=gen).to(dev)
+    monkeypatch.setenv("BTVAE_STEP_GRAPH", "0")
+    runs = {}
+    for padded in (True, False):
+        monkeypatch.setattr(E, "PITCHED_ROWS", padded)
+        torch.manual_seed(21)
+        m = CVAE(input_dim=D, conditioner=Cdim(C), **cfg).to(dev).train()
+        m.train_kwargs = {"num_mc_samples": S, "beta": 0.8, "gradient_clipping": True, "gradient_clipping_kwargs": {"max_norm": 1.0}}
+        opt = m.get_optimizer(lr=1e-3, weight_decay=1e-5)
+        torch.manual_seed(33)                     # the dropout seeds of the steps
+        losses = []
+        for _ in range(3):
+            out = m._train_step(x, c, opt, eps=eps)
+            losses.append([out[k].item() for k in ("loss", "elbo", "rll", "kl")])
+        m.eval()
+        with torch.no_grad():
+            fw = m._run_forward(x, c, S, eps=eps)
+            ev = m._loss_from_forward(fw, x, 0.8).tolist()
+        probe = E._rows_on_lines(4, H, dev)
+        assert (probe.stride(0) == 96) == padded
+        runs[padded] = (losses, ev, {k: v.detach().clone() for k, v in m.state_dict().items()})
+    assert runs[True][0] == runs[False][0], (runs[True][0], runs[False][0])
+    assert runs[True][1] == runs[False][1]
+    for k, v in runs[False][2].items():
+        assert torch.equal(v, runs[True][2][k]), k
+    from behavio_temporal_vae_amd import _native as nv
+    nv.set_gemm_precision("fp32")
+
+
 class _FixedRandn:
     """Make ``torch.randn`` return a given tensor once (the module-level API draws its own noise)."""
     def __init__(self, eps):
