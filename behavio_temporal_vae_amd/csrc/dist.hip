@@ -473,6 +473,55 @@ __global__ __launch_bounds__(256) void mvn_rows_pair_kernel(const float* __restr
     if (live && i == 0) logp[row] = -0.5f * ((float)D * LOG_2PI + maha) - 0.5f * logdet;
 }
 
+// Forward-only variant for D <= 24: one covariance per LANE, its packed lower triangle (up to 300 values) in registers.
+// The elimination then touches each element of the triangle once per pivot below it -- D^3/6 multiply-adds per row
+// instead of the D^3 a lane-per-matrix-row layout spends -- and needs no LDS and no cross-lane traffic; the kernels
+// above are bound by exactly those (every lane re-reads the whole pivot row from LDS at every step).  Same arithmetic
+// per element (symmetric elimination without pivoting, pivots in order), so the log-densities agree to rounding.
+template <int DP>
+__global__ __launch_bounds__(64) void mvn_rows_lane_kernel(const float* __restrict__ Sp, const float* __restrict__ mu,
+                                                           const float* __restrict__ x, float* __restrict__ logp,
+                                                           int rows, int B, int D) {
+    constexpr int NPP = DP * (DP + 1) / 2;
+    const int row_raw = blockIdx.x * 64 + threadIdx.x;
+    const bool live = row_raw < rows;
+    const int row = live ? row_raw : rows - 1;
+    const int NP = D * (D + 1) / 2;
+    const float* src = Sp + (size_t)row * NP;
+    float a[NPP], r[DP];
+    if (D == DP && (reinterpret_cast<uintptr_t>(Sp) & 15) == 0) {       // NPP is a multiple of 4 for DP = 8, 16, 24: rows stay 16-byte aligned
+#pragma unroll
+        for (int p = 0; p < NPP; p += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + p);
+            a[p] = v.x; a[p + 1] = v.y; a[p + 2] = v.z; a[p + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < DP; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j)
+                a[i * (i + 1) / 2 + j] = (i < D) ? src[i * (i + 1) / 2 + j] : (i == j ? 1.f : 0.f);     // identity padding
+    }
+#pragma unroll
+    for (int i = 0; i < DP; ++i) r[i] = (i < D) ? x[(size_t)(row % B) * D + i] - mu[(size_t)row * D + i] : 0.f;
+    float logdet = 0.f, maha = 0.f;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+        const float piv = a[k * (k + 1) / 2 + k];
+        logdet += logf(piv);
+        const float rp = 1.f / piv;
+        maha = fmaf(r[k] * r[k], rp, maha);
+#pragma unroll
+        for (int i = k + 1; i < DP; ++i) {
+            const float f = a[i * (i + 1) / 2 + k] * rp;
+            r[i] = fmaf(-f, r[k], r[i]);
+#pragma unroll
+            for (int j = k + 1; j <= i; ++j) a[i * (i + 1) / 2 + j] = fmaf(-f, a[j * (j + 1) / 2 + k], a[i * (i + 1) / 2 + j]);
+        }
+    }
+    if (live) logp[row] = -0.5f * ((float)D * LOG_2PI + maha) - 0.5f * logdet;
+}
+
 // ---------------------------------------------------------------------------------------------
 // ELBO scalars: out = [loss, elbo, rll, kl], rll = mean(logp), kl = mean(klrow), loss = -(rll - beta*kl)
 // ---------------------------------------------------------------------------------------------
@@ -562,6 +611,16 @@ template <bool BWD>
 int launch_mvn(int D, const float* Sp, const float* mu, const float* x, const float* dfac_mu, const float* g_rows, float g_const,
                float* logp, float* dmu_raw, float* Pg, int rows, int B, hipStream_t s) {
     dim3 grid((rows + 3) / 4), block(256);
+    static const bool no_lane = getenv("BTVAE_MVN_NO_ROW_PER_LANE") != nullptr;      // A/B switch: the two-rows-per-wave kernel
+    if (!BWD && D <= 24 && !no_lane) {
+        dim3 lgrid((rows + 63) / 64);
+#define BTVAE_MVN_LANE(DPV) hipLaunchKernelGGL((mvn_rows_lane_kernel<DPV>), lgrid, dim3(64), 0, s, Sp, mu, x, logp, rows, B, D)
+        if (D <= 8) BTVAE_MVN_LANE(8);
+        else if (D <= 16) BTVAE_MVN_LANE(16);
+        else BTVAE_MVN_LANE(24);
+#undef BTVAE_MVN_LANE
+        return btvae::check_launch("mvn_rows");
+    }
     if (!BWD && D <= 32) {
         dim3 pgrid((rows + 7) / 8);
 #define BTVAE_MVN_PAIR(DPV) hipLaunchKernelGGL((mvn_rows_pair_kernel<DPV>), pgrid, block, 0, s, Sp, mu, x, logp, rows, B, D)
