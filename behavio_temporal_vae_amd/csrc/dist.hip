@@ -611,7 +611,7 @@ template <bool BWD>
 int launch_mvn(int D, const float* Sp, const float* mu, const float* x, const float* dfac_mu, const float* g_rows, float g_const,
                float* logp, float* dmu_raw, float* Pg, int rows, int B, hipStream_t s) {
     dim3 grid((rows + 3) / 4), block(256);
-    static const bool no_lane = getenv("BTVAE_MVN_NO_ROW_PER_LANE") != nullptr;      // A/B switch: the two-rows-per-wave kernel
+    static const bool no_lane = getenv("BTVAE_MVN_FWD_PAIR") != nullptr;      // A/B switch: the two-rows-per-wave kernel
     if (!BWD && D <= 24 && !no_lane) {
         dim3 lgrid((rows + 63) / 64);
 #define BTVAE_MVN_LANE(DPV) hipLaunchKernelGGL((mvn_rows_lane_kernel<DPV>), lgrid, dim3(64), 0, s, Sp, mu, x, logp, rows, B, D)
