@@ -68,6 +68,39 @@ def _worker(rank, world, port, q):
             out[mode] = (np.array(losses), sd)
             from behavio_temporal_vae_amd import engine as E
             E.BN_SYNC = None
+        # the same with a hidden width that is not a multiple of 32 (activation and gradient rows padded to a pitch of 96):
+        # the statistics-spanning BatchNorm kernels on padded matrices, residual units included
+        from behavio_temporal_vae_amd.vae_models import CVAE as _CVAE
+        from behavio_temporal_vae_amd import engine as E
+        assert E._rows_on_lines(2, 72, dev).stride(0) == 96
+        cfgp = {"latent_dim": 6, "distribution_dict": {
+            "posterior": {"dist_type": "normal", "sigma_lim": 0.05, "mu_upper_lim": 5.0, "mu_lower_lim": -5.0, "num_neurons": 72,
+                          "num_hidden_layers": 2, "dropout": False, "batch_normalization": True},
+            "likelihood": {"dist_type": "dict-gauss", "vocab_size": 30, "sigma_lim": 1e-4, "marginal_std_lim": 0.1, "mu_lower_lim": -3,
+                           "num_neurons": 72, "num_hidden_layers": 2, "dropout": False, "batch_normalization": True}}}
+        gen = torch.Generator().manual_seed(77)
+        Bp, Sp_, Dp, Cp = 96, 3, 12, 4
+        xp = torch.randn(4, Bp, Dp, generator=gen).clamp(-3, 5).to(dev)
+        cp = torch.randn(4, Bp, Cp, generator=gen).to(dev)
+        ep = torch.randn(4, Sp_, Bp, 6, generator=gen).to(dev)
+        lo, hi = rank * Bp // world, (rank + 1) * Bp // world
+        for mode in ("single", "sync"):
+            torch.manual_seed(5)
+            m = _CVAE(input_dim=Dp, conditioner=Cdim(Cp), **cfgp).to(dev).train()
+            m.train_kwargs = {"num_mc_samples": Sp_, "beta": 0.7, "gradient_clipping": True, "gradient_clipping_kwargs": {"max_norm": 1.0}}
+            if mode == "sync":
+                m.enable_data_parallel(sync_batchnorm=True)
+            opt = m.get_optimizer(lr=1e-3, weight_decay=1e-5)
+            losses = []
+            for t in range(4):
+                x, c, eps = xp[t], cp[t], ep[t]
+                if mode == "sync":
+                    x, c, eps = x[lo:hi].contiguous(), c[lo:hi].contiguous(), eps[:, lo:hi].contiguous()
+                l = m._train_step(x, c, opt, eps=eps)
+                losses.append([l[k].item() for k in ("loss", "elbo", "rll", "kl")])
+            sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if v.is_floating_point()}
+            out["padded_" + mode] = (np.array(losses), sd)
+            E.BN_SYNC = None
         # scoring with the Monte-Carlo draws split over the ranks (same profiles on both), ragged chunks
         from behavio_temporal_vae_amd import testing_lib
         gs = load_golden("scoring_tiny")
@@ -114,6 +147,11 @@ def test_syncbn_two_ranks_equal_single_device():
             assert np.abs(sync_sd[k] - v).max() <= 5e-4 * (np.abs(v).max() + 1e-6), k
         # per-rank statistics (the default) are a different computation: the check above is not vacuous
         assert np.max(np.abs(per_l - single_l) / (np.abs(single_l) + 1e-6)) > 1e-3
+        pl, psd = out["padded_single"]
+        ql, qsd = out["padded_sync"]
+        assert np.max(np.abs(ql - pl) / (np.abs(pl) + 1e-6)) < 1e-4, (rank, ql, pl)
+        for k, v in psd.items():
+            assert np.abs(qsd[k] - v).max() <= 5e-4 * (np.abs(v).max() + 1e-6), k
     assert np.array_equal(res[0][1]["sync"][0], res[1][1]["sync"][0])        # both ranks report the same averaged terms
     # K-sharded scoring == unsharded == the reference's golden ll on every rank; the ranks' draw ranges tile K
     gs = load_golden("scoring_tiny")
