@@ -689,6 +689,8 @@ int noalloc_scratch_setup(int device) {
 BTVAE_API long long btvae_colsum_noalloc_max_floats(void) { return NOALLOC_SCRATCH_FLOATS; }
 
 BTVAE_API int btvae_colsum_noalloc(const float* G, float* out, float* cur, int M, int N, int accumulate, void* stream) {
+    BTVAE_TAKE_LD("colsum_noalloc");                   // a pending row-pitch request is this launch's, as for btvae_colsum
+    (void)take_output_maximum();                       // and a pending maximum request ends here: this kernel writes no operand
     BTVAE_REQUIRE(G && (out || cur), "colsum_noalloc: null pointer");
     BTVAE_REQUIRE(M > 0 && N > 0, "colsum_noalloc: empty problem (M=%d, N=%d)", M, N);
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
@@ -697,15 +699,16 @@ BTVAE_API int btvae_colsum_noalloc(const float* G, float* out, float* cur, int M
                   chunks, N, (long long)chunks * N, NOALLOC_SCRATCH_FLOATS);
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
-    BTVAE_REQUIRE(e == hipSuccess && dev >= 0 && dev < NOALLOC_MAX_DEVICES, "colsum_noalloc: no current device (%s)", hipGetErrorString(e));
+    BTVAE_REQUIRE(e == hipSuccess, "colsum_noalloc: no current device (%s)", hipGetErrorString(e));
+    BTVAE_REQUIRE(dev >= 0 && dev < NOALLOC_MAX_DEVICES, "colsum_noalloc: current device %d beyond the %d this library tracks", dev, NOALLOC_MAX_DEVICES);
     float* ptr = g_scratch_ptr[dev];
     BTVAE_REQUIRE(ptr != nullptr, "colsum_noalloc: btvae_init(%d) has not run on the current device", dev);
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N);
-    if (vec4_ok(N, N, G, nullptr, nullptr, nullptr))
-        hipLaunchKernelGGL((colsum_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, ptr, M, N, N, rpc);
+    if (vec4_ok(N, ld, G, nullptr, nullptr, nullptr))
+        hipLaunchKernelGGL((colsum_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, ptr, M, N, ld, rpc);
     else
-        hipLaunchKernelGGL((colsum_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, ptr, M, N, N, rpc);
+        hipLaunchKernelGGL((colsum_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, ptr, M, N, ld, rpc);
     colsum_finalize(s, ptr, chunks, 1, N, out, (float*)nullptr, cur, (float*)nullptr, accumulate);
     return check_launch("colsum_noalloc");
 }

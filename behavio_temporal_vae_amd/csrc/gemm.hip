@@ -15,7 +15,11 @@
 #include "gemm_bf16.h"
 #include "gemm_split.h"
 #include "gemm_head64.h"
+#ifdef BTVAE_EXPERIMENTS
+#include "gemm_pq256.h"      // pair-format operands (pairs.h): measured and not adopted, see tools/pairs_probe.py
+#endif
 #include <algorithm>
+#include <cstdlib>
 #include <atomic>
 
 namespace {
@@ -547,6 +551,126 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     return btvae::check_launch(what);
 }
 
+#ifdef BTVAE_EXPERIMENTS
+// ---- pair format (pairs.h) -------------------------------------------------------------------------------------------
+// One workgroup per 128 x 128 block: thread t holds columns 4 (t & 31) .. + 3 of rows (t >> 5) + 8 j.  The block's maximum
+// decides its scale before anything is written, so X and P may be the same buffer (a block's bytes are the same in both
+// formats).
+__global__ __launch_bounds__(256) void pairs_encode_kernel(const float* X, int ldx, unsigned short* P, int ldp, float* __restrict__ sc,
+                                                           int M, int N) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, r0 = blockIdx.y * 128 + (tid >> 5), c = blockIdx.x * 128 + ((tid & 31) << 2);
+    float4 v[16];
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = r0 + 8 * j;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < M && c < N) v[j] = *reinterpret_cast<const float4*>(X + (size_t)r * ldx + c);
+        m = amax4(m, v[j]);
+    }
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    const float s = btvae_pairs::pq_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (tid == 0) sc[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = r0 + 8 * j;
+        if (r < M && c < ((N + 15) & ~15)) btvae_pairs::pq_store4(P + (size_t)r * (2 * ldp), c, v[j], s);   // pad columns of the last 16-group: zeros
+    }
+}
+__global__ __launch_bounds__(256) void pairs_decode_kernel(const unsigned short* P, int ldp, const float* __restrict__ sc, float* X, int ldx,
+                                                           int M, int N) {
+    const int tid = threadIdx.x, r0 = blockIdx.y * 128 + (tid >> 5), c = blockIdx.x * 128 + ((tid & 31) << 2);
+    const float inv = btvae_pairs::pq_inv(sc[(size_t)blockIdx.y * gridDim.x + blockIdx.x]);
+    float4 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = r0 + 8 * j;
+        if (r < M && c < N) v[j] = btvae_pairs::pq_load4(P + (size_t)r * (2 * ldp), c, inv);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = r0 + 8 * j;
+        if (r < M && c < N) *reinterpret_cast<float4*>(X + (size_t)r * ldx + c) = v[j];
+    }
+}
+
+// products whose A operand is in the pair format: B pre-split into fp16 planes (a.Bp) with its maximum in a.amax_b
+template <int BL, int EPI>
+int launch_pairs(GemmArgs& a, int variant, hipStream_t s, const char* what) {
+    a.amax_a = nullptr;
+    a.amax_out = btvae::take_output_maximum();
+    if (EPI != EPI_RELU_STATS && EPI != EPI_RELU_AFFINE && EPI != EPI_BNBWD) a.amax_out = nullptr;
+    BTVAE_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "%s: empty problem M=%d N=%d K=%d", what, a.M, a.N, a.K);
+    BTVAE_REQUIRE(a.A && a.a_sc && a.Bp && a.amax_b && a.C, "%s: null operand", what);
+    BTVAE_REQUIRE(a.K % 8 == 0 && a.lda % 16 == 0 && a.lda >= a.K && aligned16(a.A), "%s: pair-format operand needs K %% 8 == 0, a 16-byte aligned base and a pitch that is a multiple of 16 (K %d, pitch %d)", what, a.K, a.lda);
+    BTVAE_REQUIRE(a.ldc >= a.N, "%s: ldc %d < N %d", what, a.ldc, a.N);
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.a_scn = (a.K + 127) / 128;
+    a.a_vec = a.b_vec = 1;
+    a.c_vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && aligned16(a.C) && (!a.R || (a.ldr % 4 == 0 && aligned16(a.R)));
+    const bool wide = variant == 1 && a.N > BN;
+    a.tiles_n = (a.N + (wide ? 2 * BN : BN) - 1) / (wide ? 2 * BN : BN);
+    a.kchunk = (a.K + SBK - 1) / SBK * SBK;
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, 1);
+    if (wide) hipLaunchKernelGGL((gemm_split_mfma<LAY_K, BL, EPI, true, 2, 2, 1>), grid, dim3(256), 0, s, a);
+    else      hipLaunchKernelGGL((gemm_split_mfma<LAY_K, BL, EPI, true, 2, 1, 1>), grid, dim3(256), 0, s, a);
+    return btvae::check_launch(what);
+}
+
+// B[n][k] (n < Nn output columns, k < Kk reduction steps) = W[n][k], or W[k][n] when `transpose`, as the stage images
+// gemm_pq256 copies into LDS: blocks [ceil(Nn/256)][ceil(Kk/16)] of 256 rows x 64 bytes (q_off), two fp16 pieces of the
+// value times the power of two *amax selects, zero padded.  One thread per row and 8-k half.
+__global__ __launch_bounds__(256) void weight_image_pq_kernel(const float* __restrict__ W, int ldw, int Nn, int Kk, int transpose,
+                                                              char* __restrict__ image, const float* __restrict__ amax) {
+    const int KT = (Kk + 15) >> 4;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)((Nn + 255) >> 8) * KT * 512) return;
+    const int c = (int)(idx & 1), nl = (int)((idx >> 1) & 255);
+    const size_t blk = idx >> 9;
+    const int kt = (int)(blk % KT), n = (int)(blk / KT) * 256 + nl, k0 = kt * 16 + c * 8;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        v[i] = (n < Nn && k0 + i < Kk) ? (transpose ? W[(size_t)(k0 + i) * ldw + n] : W[(size_t)n * ldw + k0 + i]) : 0.f;
+    const float sc = btvae_pairs::pq_scale_for(*amax);
+    unsigned P[4], Q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) btvae_pairs::pq_encode2(v[2 * i], v[2 * i + 1], sc, P[i], Q[i]);
+    char* dst = image + blk * QST_B;
+    *reinterpret_cast<uint4*>(dst + q_off(nl, c)) = make_uint4(P[0], P[1], P[2], P[3]);
+    *reinterpret_cast<uint4*>(dst + q_off(nl, c + 2)) = make_uint4(Q[0], Q[1], Q[2], Q[3]);
+}
+
+template <int EPI>
+int launch_pq256(GemmArgs& a, int groups, hipStream_t s, const char* what) {
+    a.amax_a = nullptr;
+    a.amax_out = btvae::take_output_maximum();
+    if (EPI != EPI_RELU_STATS && EPI != EPI_RELU_AFFINE && EPI != EPI_BNBWD) a.amax_out = nullptr;
+    BTVAE_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "%s: empty problem M=%d N=%d K=%d", what, a.M, a.N, a.K);
+    BTVAE_REQUIRE(a.A && a.a_sc && a.Bp && a.amax_b && a.C, "%s: null operand", what);
+    BTVAE_REQUIRE(a.lda % 16 == 0 && a.lda >= (a.K + 15) / 16 * 16 && aligned16(a.A), "%s: pair-format operand needs a 16-byte aligned base and a pitch that is a multiple of 16 covering K rounded up to 16 (K %d, pitch %d)", what, a.K, a.lda);
+    BTVAE_REQUIRE(a.ldc >= a.N, "%s: ldc %d < N %d", what, a.ldc, a.N);
+    a.tiles_m = (a.M + 128 * groups - 1) / (128 * groups);
+    a.tiles_n = (a.N + QN - 1) / QN;
+    a.a_scn = (a.K + 127) / 128;
+    a.bp_tiles = (a.K + 15) / 16;
+    a.a_vec = a.b_vec = 1;
+    a.c_vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && aligned16(a.C) && (!a.R || (a.ldr % 4 == 0 && aligned16(a.R)));
+    a.kchunk = a.bp_tiles * 16;
+#ifdef BTVAE_PQ_ABLATE
+    { const char* e = getenv("BTVAE_PQ_ABLATE"); a.lde = e ? atoi(e) : 0; }
+#endif
+    if (groups == 2) hipLaunchKernelGGL((gemm_pq256<EPI, 2>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), 0, s, a);
+    else             hipLaunchKernelGGL((gemm_pq256<EPI, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, s, a);
+    return btvae::check_launch(what);
+}
+
+#endif  // BTVAE_EXPERIMENTS
+
 int pick_splits(int tiles, int K, size_t ws_floats, size_t out_elems) {
     int want = (1024 + tiles - 1) / tiles;            // aim at ~4 workgroups per CU
     int maxk = std::max(1, K / (4 * BK));              // keep >= 4 k-tiles per split
@@ -713,6 +837,72 @@ BTVAE_API int btvae_linear_relu_stats_fwd(const float* X, int ldx, const float* 
                                           float* stat_partials, int M, int K, int N, void* stream) {
     return btvae_linear_relu_stats_fwd_pw(X, ldx, W, nullptr, b, Y, stat_partials, M, K, N, stream);
 }
+
+#ifdef BTVAE_EXPERIMENTS
+// fp32 X[M][N] (row pitch ldx) -> pair format P (the bytes of an fp32 matrix of pitch ldp, ldp % 16 == 0, N % 8 == 0) and
+// its block scales sc[ceil(M/128)][ceil(N/128)]; P may be X itself when ldp == ldx.
+BTVAE_API int btvae_pairs_encode(const float* X, int ldx, void* P, int ldp, float* sc, int M, int N, void* stream) {
+    BTVAE_REQUIRE(X && P && sc && M > 0 && N > 0, "pairs_encode: bad arguments");
+    BTVAE_REQUIRE(N % 8 == 0 && ldp % 16 == 0 && ldp >= N && ldx >= N && ldx % 4 == 0 && aligned16(X) && aligned16(P),
+                  "pairs_encode: needs N %% 8 == 0, ldp %% 16 == 0, ldx %% 4 == 0 and 16-byte aligned bases (N %d, ldx %d, ldp %d)", N, ldx, ldp);
+    BTVAE_REQUIRE((const void*)X != (const void*)P || ldx == ldp, "pairs_encode: in place needs equal pitches");
+    hipLaunchKernelGGL(pairs_encode_kernel, dim3((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128)), dim3(256), 0, (hipStream_t)stream,
+                       X, ldx, (unsigned short*)P, ldp, sc, M, N);
+    return check_launch("pairs_encode");
+}
+BTVAE_API int btvae_pairs_decode(const void* P, int ldp, const float* sc, float* X, int ldx, int M, int N, void* stream) {
+    BTVAE_REQUIRE(X && P && sc && M > 0 && N > 0, "pairs_decode: bad arguments");
+    BTVAE_REQUIRE(N % 8 == 0 && ldp % 16 == 0 && ldp >= N && ldx >= N && ldx % 4 == 0 && aligned16(X) && aligned16(P),
+                  "pairs_decode: needs N %% 8 == 0, ldp %% 16 == 0, ldx %% 4 == 0 and 16-byte aligned bases (N %d, ldx %d, ldp %d)", N, ldx, ldp);
+    BTVAE_REQUIRE((const void*)X != (const void*)P || ldx == ldp, "pairs_decode: in place needs equal pitches");
+    hipLaunchKernelGGL(pairs_decode_kernel, dim3((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)P, ldp, sc, X, ldx, M, N);
+    return check_launch("pairs_decode");
+}
+
+// btvae_linear_relu_stats_fwd_pw with X in the pair format (Xp, pitch ldx floats, block scales xsc); Wplanes are fp16
+// planes (btvae_weight_planes_f16) and wmax the maximum they were made with.  variant 1: 128 x 256 block tile.
+BTVAE_API int btvae_linear_relu_stats_fwd_pq(const void* Xp, int ldx, const float* xsc, const void* Wplanes, const float* wmax, const float* b,
+                                             float* Y, float* stat_partials, int M, int K, int N, int variant, void* stream) {
+    const RowPitches rp = take_row_pitches();
+    int ldy;
+    BTVAE_REQUIRE(pitch_of(rp.n, N, ldy), "linear_relu_stats_fwd_pq: row pitch %d below N = %d", rp.n, N);
+    BTVAE_REQUIRE(b && stat_partials, "linear_relu_stats_fwd_pq: null bias/stats");
+    GemmArgs a{}; a.A = (const float*)Xp; a.lda = ldx; a.a_sc = xsc; a.C = Y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
+    a.bias = b; a.stats = stat_partials; set_planes(a, Wplanes, N, K, false); a.amax_b = wmax;
+    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    return launch_pairs<LAY_K, EPI_RELU_STATS>(a, variant, (hipStream_t)stream, "linear_relu_stats_fwd_pq");
+}
+
+// Stage images of a weight matrix W[R][C] for the 256 x 256 pair-format products: transpose = 0 for the forward products
+// (output columns = rows of W), 1 for the dX products (output columns = columns of W).  *amax = max |W| (device scalar).
+BTVAE_API long long btvae_weight_image_pq_bytes(int R, int C, int transpose) {
+    if (R <= 0 || C <= 0) return 0;
+    const int Nn = transpose ? C : R, Kk = transpose ? R : C;
+    return (long long)((Nn + 255) / 256) * ((Kk + 15) / 16) * QST_B;
+}
+BTVAE_API int btvae_weight_image_pq(const float* W, int ldw, int R, int C, int transpose, void* image, const float* amax, void* stream) {
+    BTVAE_REQUIRE(W && image && amax && R > 0 && C > 0 && ldw >= C && aligned16(image), "weight_image_pq: bad arguments");
+    const int Nn = transpose ? C : R, Kk = transpose ? R : C;
+    const size_t threads = (size_t)((Nn + 255) / 256) * ((Kk + 15) / 16) * 512;
+    hipLaunchKernelGGL(weight_image_pq_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       W, ldw, Nn, Kk, transpose, (char*)image, amax);
+    return check_launch("weight_image_pq");
+}
+BTVAE_API int btvae_linear_relu_stats_fwd_pq256(const void* Xp, int ldx, const float* xsc, const void* Wimage, const float* wmax, const float* b,
+                                                float* Y, float* stat_partials, int M, int K, int N, int groups, void* stream) {
+    const RowPitches rp = take_row_pitches();
+    int ldy;
+    BTVAE_REQUIRE(groups == 1 || groups == 2, "linear_relu_stats_fwd_pq256: groups %d", groups);
+    BTVAE_REQUIRE(pitch_of(rp.n, N, ldy), "linear_relu_stats_fwd_pq256: row pitch %d below N = %d", rp.n, N);
+    BTVAE_REQUIRE(b && stat_partials, "linear_relu_stats_fwd_pq256: null bias/stats");
+    GemmArgs a{}; a.A = (const float*)Xp; a.lda = ldx; a.a_sc = xsc; a.C = Y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
+    a.bias = b; a.stats = stat_partials; a.Bp = (const unsigned short*)Wimage; a.amax_b = wmax;
+    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    return launch_pq256<EPI_RELU_STATS>(a, groups, (hipStream_t)stream, "linear_relu_stats_fwd_pq256");
+}
+
+#endif  // BTVAE_EXPERIMENTS
 
 // Out = relu(X W^T + b) * scale + shift (+ R): Linear+ReLU+eval-mode BatchNorm(+residual) in one pass.
 // `_ld`: the residual input and the output with row pitches of their own (ldr, ldo >= N).  Rows that start on 128-byte

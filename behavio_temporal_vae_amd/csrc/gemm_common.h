@@ -43,6 +43,8 @@ struct GemmArgs {
     // two-piece fp16 mode: absolute maxima of the operand tensors (device scalars), from which the kernel takes its scales
     const float* amax_a; const float* amax_b;
     float* amax_out;            // null, or where max |stored C| is folded in (EPI_RELU_STATS, EPI_RELU_AFFINE, EPI_BNBWD)
+    // A operand stored as fp16 pairs with one power-of-two scale per 128 x 128 block (pairs.h): a_sc[row tile][a_scn]
+    const float* a_sc; int a_scn;
     int a_vec, b_vec;
     int c_vec;                  // outputs / add-ins allow 16-byte row accesses: epilogue staged through LDS
     int tiles_m, tiles_n;
@@ -89,9 +91,11 @@ __device__ __forceinline__ void head_value(const GemmArgs& p, float raw, float& 
 }
 
 // `red` is LDS scratch of at least 6*128 floats that no wave still reads as a tile.
+// A workgroup of 512 threads runs the epilogue once per group of 256 (each on its own 128 x 128 tile and LDS region), so
+// the thread index used here is the one inside the group.
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x16 (&acc)[2][2], float* red, int m0, int n0, int tile_m, int zz) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, lh = lane >> 5;
     // ---- epilogue: accumulator element r of tile (rb,cb) is row (r&3)+8(r>>2)+4*lh, column li ----
@@ -206,7 +210,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x16 (
             }
         }
         __syncthreads();
-        if (tid < 128 && n0 + tid < p.N) {
+        if (tid < 128 && n0 + tid < p.N && m0 < p.M) {
             const float na = red[0 * 128 + tid], ma = red[1 * 128 + tid], qa = red[2 * 128 + tid];
             const float nb = red[3 * 128 + tid], mb = red[4 * 128 + tid], qb = red[5 * 128 + tid];
             const float n = na + nb;
@@ -234,7 +238,7 @@ __device__ __forceinline__ void st4(float* q, const float4 v) { *reinterpret_cas
 
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[2][2], float* lds, int m0, int n0, int tile_m, int zz) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, lh = lane >> 5;
     float* red = lds + 64 * EPL;
@@ -433,7 +437,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
         }
         __syncthreads();
         const int c = tid & 127, which = tid >> 7;     // threads 0..127: sum G, 128..255: sum G*xhat
-        if (n0 + c < p.N) {
+        if (n0 + c < p.N && m0 < p.M) {
             float t = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) t += cs[which * 1024 + q * 128 + c];
@@ -446,7 +450,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
 #pragma unroll
         for (int e = 0; e < 4; ++e) cs[(tid >> 5) * 128 + ((tid & 31) << 2) + e] = bsb[e];
         __syncthreads();
-        if (tid < 128 && n0 + tid < p.N) {
+        if (tid < 128 && n0 + tid < p.N && m0 < p.M) {
             float t = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) t += cs[q * 128 + tid];
@@ -476,7 +480,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             }
         }
         __syncthreads();
-        if (tid < 128 && n0 + tid < p.N) {
+        if (tid < 128 && n0 + tid < p.N && m0 < p.M) {
             const float na = red[0 * 128 + tid], ma = red[1 * 128 + tid], qa = red[2 * 128 + tid];
             const float nb = red[3 * 128 + tid], mb = red[4 * 128 + tid], qb = red[5 * 128 + tid];
             const float n = na + nb;

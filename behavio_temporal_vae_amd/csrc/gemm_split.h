@@ -22,6 +22,7 @@
 // 1/s_B (exact) before the epilogue.
 #pragma once
 #include "gemm_common.h"
+#include "pairs.h"
 
 namespace btvae_gemm {
 
@@ -192,6 +193,35 @@ __device__ __forceinline__ void p_g2r(const GemmArgs& p, int n0, int k0, int tid
     }
 }
 
+// Pair-format operand (pairs.h), k-contiguous: the 64 bytes a row contributes to a 16-k tile are its 8+8 high pieces and
+// 8+8 low pieces, each 16-byte piece an MFMA operand as it stands.  Pass j: thread owns row (tid >> 2) + 64 j, piece tid & 3
+// (0, 1: halves of the p plane; 2, 3: of the q plane) -- the global access pattern of the fp32 operand.  The q plane sits
+// QPAD halfwords past where a plane would end, which puts the p and q pieces of a row on different banks: the 16-byte
+// stores of 8 consecutive lanes (2 rows x 4 pieces) then cover all banks once.
+struct QStage { uint4 v[2]; };
+constexpr int QPAD = 32;
+
+template <bool FULL>
+__device__ __forceinline__ void q_g2r(const unsigned short* __restrict__ P, int ldh, int row0, int nrows, int k0, int kend,
+                                      int tid, QStage& st) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int gr = row0 + (tid >> 2) + 64 * j, c = tid & 3;
+        const unsigned short* src = P + (size_t)min(gr, nrows - 1) * ldh + ((k0 >> 4) << 5) + (c << 3);
+        uint4 a = make_uint4(0u, 0u, 0u, 0u);
+        if (FULL) a = *reinterpret_cast<const uint4*>(src);
+        else if (gr < nrows && k0 + ((c & 1) << 3) + 7 < kend) a = *reinterpret_cast<const uint4*>(src);
+        st.v[j] = a;
+    }
+}
+__device__ __forceinline__ void q_r2s(__bf16* S, int tid, const QStage& st) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (tid >> 2) + 64 * j, c = tid & 3;
+        *reinterpret_cast<uint4*>(S + (c >> 1) * (SPLANE + QPAD) + s_off(row, c & 1)) = st.v[j];
+    }
+}
+
 template <int LAY, int NPL = 3>
 __device__ __forceinline__ void p_r2s(__bf16* S, int tid, const PStage& st) {
     constexpr int PL = LAY == LAY_K ? SPLANE : MPLANE;
@@ -249,24 +279,32 @@ __device__ __forceinline__ int s_frag_off(int blk, int lane) {
 
 template <bool PRE> struct BStageOf { typedef SStage type; };
 template <> struct BStageOf<true> { typedef PStage type; };
+template <int AF> struct AStageOf { typedef SStage type; };
+template <> struct AStageOf<1> { typedef QStage type; };
 
 // BPRE: the B operand comes pre-split (p.Bp) instead of as fp32 (p.B).  NPL: pieces per operand value (3 bf16, or 2 fp16
 // of the scaled value: p.amax_a / p.amax_b point at the operand tensors' absolute maxima).  NB: 128-column sub-tiles of
 // B per workgroup (block tile 128 x 128*NB, wave tile 64 x 64*NB): with 2, one staged-and-split A tile and one barrier feed
 // twice the matrix instructions (p.tiles_n counts the 128*NB-wide tiles).
-template <int AL, int BL, int EPI, bool BPRE = false, int NPL = 3, int NB = 1>
+// AF = 1: the A operand is stored in the pair format (p.A reinterpreted, p.a_sc its block scales; k-contiguous, NPL = 2):
+// no split arithmetic for it, and its scale changes every 128 reduction steps -- the accumulators are carried in units of
+// the current block's scale and multiplied by the ratio of two scales (powers of two: exact) at each block boundary.
+template <int AL, int BL, int EPI, bool BPRE = false, int NPL = 3, int NB = 1, int AF = 0>
 __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && BL == LAY_K) ? BTVAE_SPLIT_WG_TWO : BTVAE_SPLIT_WG) void gemm_split_mfma(const GemmArgs p) {
+    static_assert(AF == 0 || (AL == LAY_K && NPL == 2), "pair-format A: k-contiguous, two pieces");
     typedef typename BStageOf<BPRE>::type BStage;
+    typedef typename AStageOf<AF>::type AStage;
+    constexpr int APAD = AF ? QPAD : 0;
     typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
     constexpr int PD = NB == 2 ? BTVAE_SPLIT_PD_WIDE : BTVAE_SPLIT_PD;
     constexpr int PLA = plane_elems<AL>(), PLB = plane_elems<BL>();
     constexpr int EPI_BF16 = (64 * EPL + 6 * 128) * 2;                 // the staged epilogue's LDS image, in 2-byte units
-    constexpr int BUF = NPL * PLA + NB * NPL * PLB;
-    constexpr int BOFF = NPL * PLA, BSUB = NPL * PLB;               // first B sub-tile inside a buffer, elements per sub-tile
+    constexpr int BUF = NPL * PLA + APAD + NB * NPL * PLB;
+    constexpr int BOFF = NPL * PLA + APAD, BSUB = NPL * PLB;               // first B sub-tile inside a buffer, elements per sub-tile
     constexpr int LDS_ELEMS = 2 * BUF > EPI_BF16 ? 2 * BUF : EPI_BF16;
     __shared__ __attribute__((aligned(16))) __bf16 smem_raw[LDS_ELEMS];
     float sc_a = 1.f, sc_b = 1.f;
-    if (NPL == 2) { sc_a = scale_for(*p.amax_a); sc_b = scale_for(*p.amax_b); }
+    if (NPL == 2) { sc_a = AF ? 1.f : scale_for(*p.amax_a); sc_b = scale_for(*p.amax_b); }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
 
@@ -305,24 +343,52 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && BL == L
             else s_r2s<BL>(S + h * BSUB, tid, b[h]);
         }
     };
-    auto publish_a = [&](__bf16* S, const SStage& a) {
-        if constexpr (NPL == 2) s_r2s2<AL>(S, tid, a, sc_a);
+    auto publish_a = [&](__bf16* S, const AStage& a) {
+        if constexpr (AF == 1) q_r2s(S, tid, a);
+        else if constexpr (NPL == 2) s_r2s2<AL>(S, tid, a, sc_a);
         else s_r2s<AL>(S, tid, a);
     };
-    auto fetch = [&](int j, SStage& a, BStage (&b)[NB]) {
+    auto fetch_a_full = [&](int k0, AStage& a) {
+        if constexpr (AF == 1) q_g2r<true>(reinterpret_cast<const unsigned short*>(p.A), 2 * p.lda, m0, p.M, k0, kend, tid, a);
+        else s_g2r<AL, true>(p.A, p.lda, m0, p.M, k0, kend, tid, a);
+    };
+    auto fetch = [&](int j, AStage& a, BStage (&b)[NB]) {
         if (j >= nk) return;
         const int k0 = kbeg + j * SBK;
         if (k0 + SBK <= kend) {
-            s_g2r<AL, true>(p.A, p.lda, m0, p.M, k0, kend, tid, a);
+            fetch_a_full(k0, a);
             fetch_b(k0, true, b);
         } else {
-            s_g2r<AL, false>(p.A, p.lda, m0, p.M, k0, kend, tid, a);
+            if constexpr (AF == 1) q_g2r<false>(reinterpret_cast<const unsigned short*>(p.A), 2 * p.lda, m0, p.M, k0, kend, tid, a);
+            else s_g2r<AL, false>(p.A, p.lda, m0, p.M, k0, kend, tid, a);
             fetch_b(k0, false, b);
+        }
+    };
+    // pair-format A: block scales of this row tile; after the last k-tile of a 128-k block the accumulators move to the
+    // next block's units
+    const float* asc = AF ? p.a_sc + (size_t)tile_m * p.a_scn : nullptr;
+    if constexpr (AF == 1) sc_a = asc[kbeg >> 7];
+    auto rescale = [&](int t) {
+        if constexpr (AF == 1) {
+            const int k1 = kbeg + (t + 1) * SBK;
+            if ((k1 & 127) == 0 && k1 < kend) {
+                const float nx = asc[k1 >> 7];
+                const float r = nx * btvae_pairs::pq_inv(sc_a);
+                sc_a = nx;
+#pragma unroll
+                for (int h = 0; h < NB; ++h)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc[h][i][j][e] *= r;
+            }
         }
     };
 
     // Register sets: tile j (j >= 1) travels in set j % PD.  Tile 0 goes straight to LDS through set 0.
-    SStage sa[PD];
+    AStage sa[PD];
     BStage sb[PD][NB];
 
     // fragment offsets of this lane (same in every plane and buffer)
@@ -335,7 +401,7 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && BL == L
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[pl][i] = s_frag<AL>(As + pl * PLA, oa[i]);
+            for (int i = 0; i < 2; ++i) a[pl][i] = s_frag<AL>(As + pl * PLA + (pl ? APAD : 0), oa[i]);
 #pragma unroll
         for (int h = 0; h < NB; ++h) {
             const __bf16* Bs = Bs0 + h * BSUB;
@@ -404,13 +470,13 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && BL == L
     const int nfull = (kend - kbeg) / SBK;
     int t0 = 0;
     if (nfull > 2 * PD) {
-        s_g2r<AL, true>(p.A, p.lda, m0, p.M, kbeg, kend, tid, sa[0]);
+        fetch_a_full(kbeg, sa[0]);
         fetch_b(kbeg, true, sb[0]);
         publish_a((smem_raw), sa[0]);
         publish_b((smem_raw) + BOFF, sb[0]);
 #pragma unroll
         for (int j = 1; j <= PD; ++j) {
-            s_g2r<AL, true>(p.A, p.lda, m0, p.M, kbeg + j * SBK, kend, tid, sa[j % PD]);
+            fetch_a_full(kbeg + j * SBK, sa[j % PD]);
             fetch_b(kbeg + j * SBK, true, sb[j % PD]);
         }
         __syncthreads();
@@ -423,7 +489,7 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && BL == L
                 publish_a((smem_raw + (cur ^ 1) * BUF), sa[(u + 1) % PD]);
                 publish_b((smem_raw + (cur ^ 1) * BUF) + BOFF, sb[(u + 1) % PD]);
                 const int k0 = kbeg + (t + 1 + PD) * SBK;
-                s_g2r<AL, true>(p.A, p.lda, m0, p.M, k0, kend, tid, sa[(u + 1) % PD]);
+                fetch_a_full(k0, sa[(u + 1) % PD]);
                 fetch_b(k0, true, sb[(u + 1) % PD]);
                 __builtin_amdgcn_sched_group_barrier(0x100, ((AL == LAY_K ? 2 : 4) + (BL == LAY_K ? 2 : 4)) * NPL, 0);   // fragment reads (A, first B sub-tile)
 #pragma unroll
@@ -433,6 +499,7 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && BL == L
                     __builtin_amdgcn_sched_group_barrier(0x002, BPRE ? BTVAE_SPLIT_VPM_PRE : BTVAE_SPLIT_VPM, 0);   // a few vector instructions
                     if (k & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // an LDS store
                 }
+                rescale(t);
                 __syncthreads();
             }
         }
@@ -460,6 +527,7 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && BL == L
                     publish_b((smem_raw + (cur ^ 1) * BUF) + BOFF, sb[(u + 1) % PD]);
                 }
                 fetch(t + 1 + PD, sa[(u + 1) % PD], sb[(u + 1) % PD]);
+                rescale(t);
                 __syncthreads();
             }
         }
@@ -472,7 +540,7 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && BL == L
             __syncthreads();                                // the previous sub-tile's epilogue is done with the LDS image
         }
         if (NPL == 2) {
-            const float ia = 1.f / sc_a, ib = 1.f / sc_b;   // powers of two: exact, applied one after the other to stay in range
+            const float ia = AF ? btvae_pairs::pq_inv(sc_a) : 1.f / sc_a, ib = 1.f / sc_b;   // powers of two: exact, applied one after the other to stay in range
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll

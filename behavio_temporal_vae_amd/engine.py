@@ -90,6 +90,7 @@ class Saved:
     readers_done: int = 0                    # of which have run their dX product in the backward
     g_partials: Optional[tuple] = None       # (partials, row tiles) of sum G, sum G*xhat left by the last reader's dX product
     w_planes: Optional[torch.Tensor] = None  # bf16 planes of the unit's (unfolded) weight for the dX product, split mode
+    synced: bool = False                     # the statistics were merged over a process group: the backward sums are too
 
 
 class NetPlan:
@@ -206,14 +207,22 @@ class _MaxSlots:
 
     def __init__(self):
         self.chunk, self.used = None, 0
+        self.held, self.held_prev = [], []
 
     def fresh(self):
         """Start a new chunk with the next slot.  Every pass does: a pass captured into a HIP graph must zero its slots
-        inside the graph, or a replay would extend the previous replay's maxima instead of taking its own."""
+        inside the graph, or a replay would extend the previous replay's maxima instead of taking its own.
+        The chunks of the pass that ends here stay referenced until the end of the next one: a product is handed raw
+        pointers into them (``_operand_maxima``), possibly through views that die before its launch is enqueued, and
+        memory the allocator has taken back could be zero-filled for someone else in between."""
+        self.held_prev = self.held + ([self.chunk] if self.chunk is not None else [])
+        self.held = []
         self.chunk = None
 
     def take(self, dev) -> torch.Tensor:
         if self.chunk is None or self.used == self.CHUNK or self.chunk.device != dev:
+            if self.chunk is not None:
+                self.held.append(self.chunk)
             self.chunk, self.used = torch.zeros(self.CHUNK, device=dev), 0      # a fill kernel (a memset node in a captured
                                                                                  # graph does not hold its place: btvae_slots_zero)
         self.used += 1
@@ -430,7 +439,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         track = u.bn.track_running_stats and u.bn.running_mean is not None
         mom = u.bn.momentum if u.bn.momentum is not None else 0.1
         total_rows = M
-        if BN_SYNC is not None and BN_SYNC.world > 1:
+        if BN_SYNC is not None:
             local = torch.empty(2, N, device=dev)
             nv.call("btvae_bn_stats_local", P(part), tiles, M, N, P(local))
             parts = BN_SYNC.gather_stats(local)
@@ -446,7 +455,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         normed = keep_normed and FOLD_BN_INTO_CONSUMER and keep is None and not u.residual
         out_pr = BwdProducts(N, dev) if (normed and saved is not None) else None
         if saved is not None:
-            saved.append(Saved(x, y, mean, invstd, keep, ks, total_rows, x_sc, x_sh, x_pr, out_pr, x_src, w_planes=wp_bwd))
+            saved.append(Saved(x, y, mean, invstd, keep, ks, total_rows, x_sc, x_sh, x_pr, out_pr, x_src, w_planes=wp_bwd, synced=BN_SYNC is not None))
             if out_pr is not None:
                 out_pr.owner = (u, saved[-1])
         if normed:
@@ -610,7 +619,7 @@ def _dgrad_with_producer_backward(pr: BwdProducts, dy: torch.Tensor, W: torch.Te
     sums = torch.empty(2, Np, device=dev)
     nv.call("btvae_bn_bwd_sums_from_products", P(pr.wp), P(pr.wb), P(sv_p.mean), P(sv_p.invstd),
             P(_grad_view(u_p.bn.weight)), P(_grad_view(u_p.bn.bias)), P(sums), Np, int(accumulate))
-    if sv_p.total_rows > M:
+    if sv_p.synced:
         BN_SYNC.sum_(sums)
     tiles = (M + 127) // 128
     dpre = _rows_like(sv_p.y)
@@ -656,7 +665,7 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
         sums = torch.empty(2, N, device=dev)
         nv.call("btvae_bn_bwd_sums_from_products", P(pr.wp), P(pr.wb), P(sv.mean), P(sv.invstd),
                 P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)), P(sums), N, int(accumulate))
-        if sv.total_rows > M:
+        if sv.synced:
             BN_SYNC.sum_(sums)
         _track_output(dpre)
         _pitches(n=sv.y, same_n=(g, dpre))
@@ -667,13 +676,13 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
         part, tiles = sv.g_partials
         sums = torch.empty(2, N, device=dev)
         nv.call("btvae_bn_bwd_sums_from_partials", P(part), tiles, N, P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)), P(sums), int(accumulate))
-        if sv.total_rows > M:
+        if sv.synced:
             BN_SYNC.sum_(sums)
         _track_output(dpre)
         _pitches(n=sv.y, same_n=(g, dpre))
         nv.call("btvae_bn_relu_bwd_apply", PR(g), PR(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), None, 1.0,
                 P(sums), int(max(sv.total_rows, M)), P(_grad_view(u.lin.bias)), P(db_cur), PR(dpre), P(scr), M, N, int(accumulate))
-    elif sv.total_rows > M:
+    elif sv.synced:
         # statistics span ranks: local column sums -> sum over ranks -> dPre with the batch-wide sums
         sums = torch.empty(2, N, device=dev)
         _pitches(n=sv.y, same_n=(g,))

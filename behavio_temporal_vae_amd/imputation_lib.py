@@ -90,6 +90,10 @@ def _conditional(model, param_dict, x_observed, observed_indices, eps=None, spli
     if isinstance(model, submodels.DictionaryGaussian):
         sg_r = nv.f32(param_dict["sigma"].reshape(-1, model.vocab_size))
         if x_full is None or x_full.shape != mu_r.shape or not x_full.is_contiguous() or x_full.dtype != torch.float32:
+            if x_observed is None:                      # a chain handed its whole profile tensor in a form the kernel does not read
+                if x_full is None:
+                    raise ValueError("conditional parameters need the observed values: pass x_observed or x_full")
+                x_observed = x_full.reshape(-1, D)[:, split.obs_index]
             xo = x_observed.expand(*lead, len(obs)).reshape(-1, len(obs))
             x_full = torch.zeros(mu_r.shape[0], D, device=mu.device)
             x_full[:, split.obs_index] = xo.float()

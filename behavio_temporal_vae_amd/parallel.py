@@ -82,9 +82,12 @@ class BatchNormSync:
     """Cross-rank BatchNorm statistics (``torch.nn.SyncBatchNorm`` semantics): with it, N ranks on 1/N of the batch
     each compute what one device computes on the whole batch.  Every rank must hold the same number of rows."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # ``force``: run the collectives at world size 1 as well (identities there): exercises the RCCL calls and their
+        # ordering against the library's kernels on a single GPU
+        self.active = dist.is_initialized() and (self.world > 1 or force)
 
     def gather_stats(self, local: torch.Tensor) -> torch.Tensor:      # [2, N] -> [world, 2, N]
         return all_gather_rows(local, self.group)
@@ -97,13 +100,14 @@ class GradSync:
     """Asynchronous sum all-reduce of arena spans; ``finish`` waits for all of them.  The caller divides by
     ``world`` afterwards (on the GPU with the library's scale kernel)."""
 
-    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, force: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized() and (self.world > 1 or force)     # ``force``: see BatchNormSync
         self._handles: List = []
 
     def launch(self, span: torch.Tensor):
-        if self.world > 1:
+        if self.active:
             if span.is_cuda and _staged(self.group):
                 all_reduce_sum_(span, self.group)
             else:
@@ -115,7 +119,7 @@ class GradSync:
         self._handles = []
 
     def sum_(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world > 1:
+        if self.active:
             all_reduce_sum_(t, self.group)
         return t
 

@@ -198,6 +198,8 @@ class VAE(torch.nn.Module):
         self._arena = None
         self._grad_arena = None
         self._dp_world = 1
+        self._dp_active = False
+        self._bn_sync = None
         # operand precision of the Linear products: "fp32_split2" (default: two per-tensor-scaled fp16 pieces per value, 3
         # matrix instructions per product, error against fp64 at the fp32 MFMA instruction's level), "fp32_split" (three bf16
         # pieces: the fp32 values exactly, 6 matrix instructions), "fp32" (the fp32 MFMA instruction) or "bf16"; an extra keyword of the model config, swallowed by the reference's
@@ -471,21 +473,25 @@ class VAE(torch.nn.Module):
         return out
 
     # ------------------------------------------------------------------ data parallel hooks
-    def enable_data_parallel(self, process_group=None, sync_batchnorm=False):
+    def enable_data_parallel(self, process_group=None, sync_batchnorm=False, force_collectives=False):
         """Average gradients (and the reported loss terms) over the ranks of ``process_group`` (RCCL) in
         every ``train_core``.  Decoder gradients are reduced while the encoder backward still runs.
         ``sync_batchnorm=True`` also makes the BatchNorm statistics span the ranks (equal rows per rank), so N ranks
         on 1/N of a batch each reproduce the single-device step on the whole batch; the default keeps them per
-        rank, as ``DistributedDataParallel`` over the reference's modules would."""
+        rank, as ``DistributedDataParallel`` over the reference's modules would.  ``force_collectives=True`` issues
+        every collective in a group of one rank as well, where each is an identity: the step must then equal the
+        plain single-device step bit for bit, which is how the RCCL call sequence is tested on one GPU."""
         from .parallel import BatchNormSync, GradSync
-        self._dp_sync = GradSync(process_group)
+        self._dp_sync = GradSync(process_group, force=force_collectives)
         self._dp_world = self._dp_sync.world
-        E.BN_SYNC = BatchNormSync(process_group) if (sync_batchnorm and self._dp_world > 1) else None
+        self._dp_active = self._dp_sync.active
+        bn = BatchNormSync(process_group, force=force_collectives) if sync_batchnorm else None
+        self._bn_sync = bn if (bn is not None and bn.active) else None      # installed in the engine for this model's steps only
 
     def _grads_ready(self, which: str, part: str):
         """Start the sum all-reduce of the gradients that have just been enqueued: a network's heads (and the decoder's
         dictionary) once their backward is issued, its trunk after the trunk's."""
-        if self._dp_world <= 1:
+        if not self._dp_active:
             return
         lo, t0, t1, hi = self._net_spans[which]
         if part == "trunk":
@@ -496,7 +502,7 @@ class VAE(torch.nn.Module):
                     self._dp_sync.launch(self._grad_arena[a:b])
 
     def _dp_finish(self, scalars: torch.Tensor):
-        if self._dp_world <= 1:
+        if not self._dp_active:
             return scalars
         self._dp_sync.finish()
         nv.call("btvae_scale", nv.ptr(self._grad_arena), self._grad_arena.numel(), 1.0 / self._dp_world)
@@ -526,8 +532,12 @@ class VAE(torch.nn.Module):
             optim.step()
 
     def _train_step_eager(self, x, c, optim, eps=None):
-        fw = self._run_forward(x, c, self.train_kwargs["num_mc_samples"], eps=eps, tape=True)
-        out = self._loss_and_backward(fw, x, self.train_kwargs["beta"])
+        prev, E.BN_SYNC = E.BN_SYNC, (self._bn_sync if self._bn_sync is not None else E.BN_SYNC)
+        try:
+            fw = self._run_forward(x, c, self.train_kwargs["num_mc_samples"], eps=eps, tape=True)
+            out = self._loss_and_backward(fw, x, self.train_kwargs["beta"])
+        finally:
+            E.BN_SYNC = prev
         out = self._dp_finish(out)
         self._optim_step(optim)
         return out
@@ -537,7 +547,7 @@ class VAE(torch.nn.Module):
         data parallelism, dropout (its seeds are drawn on the host), sampled 3-D conditions, per-launch event timing, a
         stock torch optimiser, clipping options the fused step does not cover, or more rows than the launch-bound regime."""
         mode = os.environ.get("BTVAE_STEP_GRAPH", "auto")
-        if mode == "0" or self._dp_world > 1 or E.BN_SYNC is not None or not self.training:
+        if mode == "0" or self._dp_active or self._bn_sync is not None or E.BN_SYNC is not None or not self.training:
             return None
         if eps is not None and (eps.dtype != torch.float32 or eps.device != x.device):
             return None
@@ -564,7 +574,8 @@ class VAE(torch.nn.Module):
             return None
         return (tuple(x.shape), tuple(c.shape), S, float(tk["beta"]), self.gemm_precision, id(optim), self._arena.data_ptr(),
                 ck.get("max_norm") if clip else None, E.FOLD_BN_INTO_CONSUMER, E.BWD_SUMS_FROM_CONSUMERS,
-                None if eps is None else tuple(eps.shape))
+                None if eps is None else tuple(eps.shape),
+                tuple((off, cnt) for off, cnt, _ in optim._spans()))      # the captured optimiser launches: one span or two
 
     def _train_step(self, x, c, optim, eps=None):
         key = self._graph_key(x, c, optim, eps)
@@ -773,6 +784,8 @@ class CVAE(VAE):
         self._arena = None
         self._grad_arena = None
         self._dp_world = 1
+        self._dp_active = False
+        self._bn_sync = None
         self.gemm_precision = DEFAULT_GEMM_PRECISION
         self.set_gemm_precision(_.get("gemm_precision", DEFAULT_GEMM_PRECISION))
         self._finish_init()

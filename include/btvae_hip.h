@@ -129,7 +129,7 @@ int btvae_matmul_nn_mul(const float* A, int lda, const float* B, int ldb, const 
 /* Activation and gradient matrices with a row pitch (no counterpart in the reference, whose tensors are dense).  The
  * next launch, from the calling thread, of btvae_linear_relu_stats_fwd* (Y), btvae_bn_apply_fwd (Y, R, Out),
  * btvae_linear_dgrad* (dY), btvae_linear_dgrad_bnbwd* / _gstats* (dY; R, Yb, dPre / dX), btvae_linear_wgrad / _affine (dY),
- * btvae_bn_relu_bwd / _sums / _apply and btvae_relu_bwd (G, Y, dPre) or btvae_colsum (G) takes the rows of those [M, N]
+ * btvae_bn_relu_bwd / _sums / _apply and btvae_relu_bwd (G, Y, dPre) or btvae_colsum / btvae_colsum_noalloc (G) takes the rows of those [M, N]
  * matrices to be ld_n floats apart and the rows of the [M, K] ones ld_k apart (0 = dense; at least the matrix's width;
  * arguments that have a leading dimension of their own -- ldx, ldy, lddx -- keep it; dropout keep flags stay dense).
  * Width-1000 rows that start on 128-byte lines (pitch 1024) make the products that read them 6-11 % faster. */
@@ -188,7 +188,8 @@ int btvae_colsum(const float* G, float* out, float* cur, float* scratch, int M, 
  * hipMalloc).  No counterpart in the reference.  Takes no workspace and allocates nothing: the strip partials live in a
  * static 4 MiB device array inside the library, one copy per GPU, whose address btvae_init(device) resolves.  Rejects
  * btvae_strip_chunks(M) * N > btvae_colsum_noalloc_max_floats() (1,048,576).  All calls on one GPU share the array: calls
- * that overlap on different streams of the same GPU race; successive calls on one stream are safe. */
+ * that overlap on different streams of the same GPU race; successive calls on one stream are safe.  Like btvae_colsum it
+ * consumes a pending btvae_next_row_pitches request (ld_n = row pitch of G). */
 long long btvae_colsum_noalloc_max_floats(void);
 int btvae_colsum_noalloc(const float* G, float* out, float* cur, int M, int N, int accumulate, void* stream);
 /* A Linear[N,K] fed by a train-mode BatchNorm (src/submodels.py:15-21 followed by the next block's Linear, :30-34,
