@@ -37,6 +37,7 @@ _SIGS = {
     "btvae_weight_planes_f16_multi": [P, P, P, P, P, P, I, P],
     "btvae_absmax": [P, LL, P, P],
     "btvae_slots_zero": [P, I, P],
+    "btvae_guard_check": [P, P, I, P],
     "btvae_linear_head_fwd": [P, I, P, P, I, F, F, P, P, P, I, I, I, P],
     "btvae_linear_head_fwd_ws": [P, I, P, P, I, F, F, P, P, P, P, LL, I, I, I, P],
     "btvae_linear_dgrad": [P, P, P, P, I, I, I, I, P],
@@ -100,6 +101,10 @@ _RET = {
     "btvae_prof_enabled": (c_int, []),
     "btvae_gemm_operand_maxima": (c_int, [P, P]),
     "btvae_output_maximum": (c_int, [P]),
+    "btvae_gemm_guard_site": (c_int, [I]),
+    "btvae_guard_sites": (c_int, []),
+    "btvae_guard_range_log2": (c_int, [I]),
+    "btvae_guard_flags": (ctypes.POINTER(c_int), []),
     "btvae_next_row_pitches": (c_int, [I, I]),
 }
 EXPORTS = sorted(list(_SIGS) + list(_RET))
@@ -189,6 +194,7 @@ def call(name: str, *args):
         # a request meant for the launch that did not happen must not reach a later one
         lib().btvae_gemm_operand_maxima(None, None)
         lib().btvae_output_maximum(None)
+        lib().btvae_gemm_guard_site(-1)
         lib().btvae_next_row_pitches(0, 0)
         raise RuntimeError(f"{name}: {msg}")
 

@@ -37,6 +37,16 @@ struct ProfScope {
 // returns it and clears the request.
 float* take_output_maximum();
 
+// Guard of the two-piece products.  A maximum slot is TWO floats: [0] = max |x|, [1] = a range statistic, the largest
+// of (0x7f800000 - bit pattern of a region's own non-zero maximum) over the regions (waves or workgroups of the producer)
+// that contributed -- zero-initialised like the maximum, and larger the smaller some region's maximum is.  A product whose
+// operand has a region more than 2^guard_range_log2() below the tensor's maximum, or whose accumulators come out non-finite,
+// records that in its site's entry of a host-visible flag array (btvae_guard_flags); take_guard_site returns the device
+// address of the entry named for the next launch (btvae_gemm_guard_site) and clears the request.
+constexpr int GUARD_SITES = 2048;
+int guard_range_log2();          // the range (log2) beyond which a region counts as far below its tensor's maximum
+int* take_guard_site();
+
 // Row pitches (in floats; 0 = dense) that the next launch from this thread applies to its activation / gradient matrices
 // with N and with K columns (btvae_next_row_pitches); the call returns them and clears the request.
 struct RowPitches { int n, k; };
@@ -82,9 +92,24 @@ __device__ __forceinline__ float wave_max(float v) {
 // *out = max(*out, m) for non-negative m (non-negative floats order like their bit patterns: an integer atomic), skipped
 // when the slot, read past the CU's own cache, already holds as much: atomics on one address -- and on neighbouring
 // slots, one cache line -- are served one at a time, ~10 ns each, so what matters is how few of them are issued
+// The same call folds the region's maximum into the slot's range statistic out[1] (see the guard above).
 __device__ __forceinline__ void amax_commit(float m, float* out) {
-    if (m > 0.f && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    if (!(m > 0.f)) return;
+    if (m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+    const unsigned bits = __float_as_uint(m);
+    if (bits < 0x7f800000u) {
+        unsigned* q = reinterpret_cast<unsigned*>(out) + 1;
+        const unsigned inv = 0x7f800000u - bits;
+        if (inv > __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(q, inv);
+    }
+}
+// Does the slot say that some region of the tensor lies more than 2^range_log2 below the tensor's maximum?
+__device__ __forceinline__ bool slot_range_exceeded(const float* slot, int range_log2) {
+    const unsigned mx = __float_as_uint(slot[0]), inv = __float_as_uint(slot[1]);
+    if (inv == 0u || mx >= 0x7f800000u) return false;                  // no statistic / non-finite maximum (caught elsewhere)
+    const unsigned lo = 0x7f800000u - inv;                             // bit pattern of the smallest regional maximum
+    return mx > lo && ((mx - lo) >> 23) >= (unsigned)range_log2;
 }
 // fold a lane-private non-negative maximum into *out (null: nothing): one atomic per wave at most
 __device__ __forceinline__ void wave_amax_commit(float m, float* out) {

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <vector>
 #include <mutex>
+#include <atomic>
 
 namespace btvae {
 
@@ -66,6 +67,31 @@ float* take_output_maximum() { float* p = t_out_max; t_out_max = nullptr; return
 static thread_local RowPitches t_pitches = {0, 0};
 RowPitches take_row_pitches() { const RowPitches p = t_pitches; t_pitches = RowPitches{0, 0}; return p; }
 
+// guard flags: host memory the GPU writes (mapped, coherent), two ints per site: [2 s] range exceeded, [2 s + 1] non-finite
+static int* g_guard_host = nullptr;
+static int* g_guard_dev = nullptr;
+static thread_local int t_guard_site = -1;
+static std::atomic<int> g_guard_log2{16};
+int guard_range_log2() { return g_guard_log2.load(std::memory_order_relaxed); }
+int* take_guard_site() {
+    const int s = t_guard_site;
+    t_guard_site = -1;
+    return (s >= 0 && g_guard_dev) ? g_guard_dev + 2 * s : nullptr;
+}
+static int guard_setup() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_guard_host) return 0;
+    void* h = nullptr;
+    hipError_t e = hipHostMalloc(&h, sizeof(int) * 2 * GUARD_SITES, hipHostMallocMapped | hipHostMallocPortable);
+    BTVAE_REQUIRE(e == hipSuccess && h, "btvae_init: host-visible guard flags: %s", hipGetErrorString(e));
+    memset(h, 0, sizeof(int) * 2 * GUARD_SITES);
+    void* d = nullptr;
+    e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess || !d) { (void)hipHostFree(h); return set_error("btvae_init: device address of the guard flags: %s", hipGetErrorString(e)); }
+    g_guard_host = (int*)h; g_guard_dev = (int*)d;
+    return 0;
+}
+
 int noalloc_scratch_setup(int device);     // bn.hip: device address of the static scratch array on the current device
 
 }  // namespace btvae
@@ -91,9 +117,32 @@ BTVAE_API int btvae_init(int device) {
     BTVAE_REQUIRE(e == hipSuccess, "btvae_init: hipGetDevice failed: %s", hipGetErrorString(e));
     e = hipSetDevice(device);
     BTVAE_REQUIRE(e == hipSuccess, "btvae_init: hipSetDevice failed: %s", hipGetErrorString(e));
-    const int rc = noalloc_scratch_setup(device);
+    int rc = noalloc_scratch_setup(device);
+    if (!rc) rc = guard_setup();
     if (prev != device) (void)hipSetDevice(prev);
     return rc;
+}
+
+// Guard of the two-piece products (precision mode 3).  btvae_guard_flags: host address of 2 * btvae_guard_sites() ints the
+// GPU writes (host memory mapped into the device; allocated by the first btvae_init): entry [2 s] becomes non-zero when a
+// product launched for site s found an operand with a region more than 2^16 (btvae_guard_range_log2) below the tensor's maximum (its small values
+// keep an absolute, not a relative, error in this mode: run that product without maxima from then on), entry [2 s + 1]
+// when its accumulators came out non-finite (a maximum smaller than the data overflows fp16: an error).  The caller
+// reads them whenever it likes -- what it sees is final for launches that have completed -- and clears what it has handled.
+// btvae_gemm_guard_site names the site of the NEXT product launched from the calling thread (consumed by it; -1 = none).
+BTVAE_API int btvae_guard_sites(void) { return GUARD_SITES; }
+// The range test's threshold (log2; default 16, process-wide): a region whose own maximum is 2^16 below the tensor's holds
+// elements ~2^19 below it, which two scaled fp16 pieces still represent to ~2^-21 of their magnitude.
+BTVAE_API int btvae_guard_range_log2(int log2_range) {
+    BTVAE_REQUIRE(log2_range >= 1 && log2_range <= 40, "guard_range_log2: %d out of range (1..40)", log2_range);
+    g_guard_log2.store(log2_range, std::memory_order_relaxed);
+    return 0;
+}
+BTVAE_API int* btvae_guard_flags(void) { return g_guard_host; }
+BTVAE_API int btvae_gemm_guard_site(int site) {
+    BTVAE_REQUIRE(site >= -1 && site < GUARD_SITES, "gemm_guard_site: site %d out of range (%d sites)", site, GUARD_SITES);
+    t_guard_site = site;
+    return 0;
 }
 
 // The next launch, from the calling thread, of a kernel that writes an operand of a later Linear product -- the forward

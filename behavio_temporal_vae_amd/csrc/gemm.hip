@@ -437,30 +437,40 @@ inline long long planes_d_elems(int N, int K) { return (long long)((K + 127) / 1
 // absolute maximum of n floats folded into *out with an integer atomic maximum on the bit pattern (non-negative floats
 // order like their bits); *out must hold a non-negative value -- zero, or a maximum to extend -- beforehand.  NaNs are
 // skipped (fmaxf), infinities kept.
+// Each workgroup takes one contiguous run of the tensor, so that its maximum is a region's (the slot's range statistic).
 __device__ __forceinline__ void absmax_body(const float* __restrict__ x, size_t n, float* __restrict__ out) {
-    const size_t n4 = n >> 2, step = (size_t)gridDim.x * 256;
     float m = 0.f;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const size_t n4 = n >> 2, per = (n4 + gridDim.x - 1) / gridDim.x;
+        const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
         const float4* x4 = reinterpret_cast<const float4*>(x);
-        for (; i + 3 * step < n4; i += 4 * step) {           // four loads in flight per thread
-            const float4 a = x4[i], b = x4[i + step], c = x4[i + 2 * step], d = x4[i + 3 * step];
+        size_t i = lo + threadIdx.x;
+        for (; i + 768 < hi; i += 1024) {                    // four loads in flight per thread
+            const float4 a = x4[i], b = x4[i + 256], c = x4[i + 512], d = x4[i + 768];
             m = amax4(amax4(amax4(amax4(m, a), b), c), d);
         }
-        for (; i < n4; i += step) m = amax4(m, x4[i]);
-        for (size_t j = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += step) m = fmaxf(m, fabsf(x[j]));
+        for (; i < hi; i += 256) m = amax4(m, x4[i]);
+        if (blockIdx.x == gridDim.x - 1)
+            for (size_t j = (n4 << 2) + threadIdx.x; j < n; j += 256) m = fmaxf(m, fabsf(x[j]));
     } else {
-        for (; i < n; i += step) m = fmaxf(m, fabsf(x[i]));
+        const size_t per = (n + gridDim.x - 1) / gridDim.x;
+        const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+        for (size_t i = lo + threadIdx.x; i < hi; i += 256) m = fmaxf(m, fabsf(x[i]));
     }
     block_amax_commit(m, out);
 }
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) { absmax_body(x, n, out); }
 
-// Maximum slots are cleared by a kernel, never by hipMemsetAsync: under stream capture a memset becomes a memset node, and
-// replays of a training step captured with such nodes in front of the atomics left slots holding earlier contents now and
-// then (scales far too small, gradients flushed to zero, training diverging after some hundred replays).  Kernel nodes
-// keep their stream order.
+// Maximum slots are cleared by a kernel, never by hipMemsetAsync.  What was observed: with the slots of a captured
+// training step cleared by hipMemsetAsync (memset nodes in the graph), replays left slots holding earlier contents now and
+// then (scales far too small, gradients flushed to zero, training diverging after some hundred replays); with this kernel
+// in their place the replayed run repeats the eager one.  What an isolated experiment shows (tools/memset_graph_probe.hip,
+// ROCm 7.2): a memset node in front of an atomicMax kernel, captured on one stream, has the expected edges and clears an
+// ordinary device buffer in each of 20,000 replays; the same node on memory from a MEM_ALLOC node of the same graph
+// (hipMallocAsync under capture) has the same edges and clears NOTHING on any replay.  Which of the two the engine's
+// slots were (they came from the framework's capture-time pool) was not established, so the cause of the original
+// failure is not either; a kernel node is correct in both situations.
 struct SlotRuns { float* p[16]; int n[16]; };
 __global__ __launch_bounds__(64) void slots_zero_kernel(const SlotRuns r) {
     float* p = r.p[blockIdx.x];
@@ -481,6 +491,9 @@ template <int AL, int BL, int EPI> constexpr bool has_twopiece() {
 // absolute maxima of the operands of the next product launched from this thread (two-piece mode); consumed by it
 thread_local const float* t_amax_a = nullptr;
 thread_local const float* t_amax_b = nullptr;
+}
+extern "C" int btvae_gemm_guard_site(int site);
+namespace {
 
 // which kernels exist with a pre-split B operand: the Linear forward products and the dX products
 template <int AL, int BL, int EPI> constexpr bool has_presplit() {
@@ -500,6 +513,8 @@ template <int AL, int BL, int EPI>
 int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduced_ok = false) {
     a.amax_a = t_amax_a; a.amax_b = t_amax_b;
     t_amax_a = t_amax_b = nullptr;
+    a.guard = btvae::take_guard_site();
+    a.guard_log2 = btvae::guard_range_log2();
     a.amax_out = btvae::take_output_maximum();
     if (EPI != EPI_RELU_STATS && EPI != EPI_RELU_AFFINE && EPI != EPI_BNBWD) a.amax_out = nullptr;
     BTVAE_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "%s: empty problem M=%d N=%d K=%d", what, a.M, a.N, a.K);
@@ -745,6 +760,21 @@ BTVAE_API int btvae_slots_zero(float* slots, int n, void* stream) {
     return check_launch("slots_zero");
 }
 
+// The range test a two-piece product makes on its operands' slots, as a launch of its own: flags[0] = 1 when either
+// tensor has a region more than 2^btvae_guard_range_log2 below its maximum.  For callers that want the verdict before they launch the product
+// (they synchronise and read the flag) instead of from the product itself.
+__global__ void guard_check_kernel(const float* a, const float* b, int* flags, int range_log2) {
+    if ((a && slot_range_exceeded(a, range_log2)) || (b && slot_range_exceeded(b, range_log2))) flags[0] = 1;
+}
+BTVAE_API int btvae_guard_check(const float* amax_a, const float* amax_b, int site, void* stream) {
+    BTVAE_REQUIRE(site >= 0 && site < btvae::GUARD_SITES, "guard_check: site %d out of range", site);
+    { const int rc = btvae_gemm_guard_site(site); if (rc) return rc; }
+    int* flags = btvae::take_guard_site();
+    BTVAE_REQUIRE(flags, "guard_check: btvae_init has not run");
+    hipLaunchKernelGGL(guard_check_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, amax_a, amax_b, flags, btvae::guard_range_log2());
+    return check_launch("guard_check");
+}
+
 // Absolute maxima (device scalars) of the A and B operand tensors of the NEXT product launched from the calling thread;
 // that launch consumes them.  In precision mode 3 a Linear-layer product that has both runs with two fp16 pieces per
 // value; one without, or any product in another mode, ignores them.  Each maximum must cover every element the product
@@ -798,8 +828,8 @@ BTVAE_API int btvae_weight_planes_f16_multi(const float* const* W, const int* N,
         int nruns = 0;
         for (int i = 0; i < n; ++i) {                        // slots that are neighbours in memory are cleared as one run
             const int j = base + i;
-            if (i > 0 && amax[j] == amax[j - 1] + 1) ++runs.n[nruns - 1];
-            else { runs.p[nruns] = amax[j]; runs.n[nruns] = 1; ++nruns; }
+            if (i > 0 && amax[j] == amax[j - 1] + 2) runs.n[nruns - 1] += 2;
+            else { runs.p[nruns] = amax[j]; runs.n[nruns] = 2; ++nruns; }
         }
         hipLaunchKernelGGL(slots_zero_kernel, dim3((unsigned)nruns), dim3(64), 0, (hipStream_t)stream, runs);
         const unsigned blocks = (unsigned)std::min<size_t>((most / 16 + 255) / 256 + 1, 32);

@@ -45,6 +45,8 @@ struct GemmArgs {
     float* amax_out;            // null, or where max |stored C| is folded in (EPI_RELU_STATS, EPI_RELU_AFFINE, EPI_BNBWD)
     // A operand stored as fp16 pairs with one power-of-two scale per 128 x 128 block (pairs.h): a_sc[row tile][a_scn]
     const float* a_sc; int a_scn;
+    int* guard;                 // two-piece mode: this product's entry of the guard flags ([0] range, [1] non-finite), or null
+    int guard_log2;             // threshold of the range test
     int a_vec, b_vec;
     int c_vec;                  // outputs / add-ins allow 16-byte row accesses: epilogue staged through LDS
     int tiles_m, tiles_n;

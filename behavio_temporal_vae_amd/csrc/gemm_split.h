@@ -306,6 +306,11 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && BL == L
     float sc_a = 1.f, sc_b = 1.f;
     if (NPL == 2) { sc_a = AF ? 1.f : scale_for(*p.amax_a); sc_b = scale_for(*p.amax_b); }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (NPL == 2 && p.guard && blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) {
+        // an operand with a region far below its tensor's maximum: say so (the host routes this product to the
+        // three-piece kernel from then on)
+        if ((!AF && slot_range_exceeded(p.amax_a, p.guard_log2)) || slot_range_exceeded(p.amax_b, p.guard_log2)) p.guard[0] = 1;
+    }
     const int wr = wid >> 1, wc = wid & 1;
 
     int zz;
@@ -538,6 +543,18 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && BL == L
         if (h > 0) {
             if (n0 + h * BN >= p.N) break;                  // uniform: the sub-tile lies past the last column
             __syncthreads();                                // the previous sub-tile's epilogue is done with the LDS image
+        }
+        if (NPL == 2 && p.guard) {
+            // an operand maximum smaller than the data overflows fp16 and leaves infinities / NaNs here, which the ReLU
+            // epilogues would silently turn into zeros
+            unsigned worst = 0u;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) worst = max(worst, __float_as_uint(acc[h][i][j][r]) & 0x7fffffffu);
+            if (worst >= 0x7f800000u) p.guard[1] = 1;
         }
         if (NPL == 2) {
             const float ia = AF ? btvae_pairs::pq_inv(sc_a) : 1.f / sc_a, ib = 1.f / sc_b;   // powers of two: exact, applied one after the other to stay in range

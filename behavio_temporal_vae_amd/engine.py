@@ -203,7 +203,7 @@ class _MaxSlots:
     """Device scalars for the absolute maxima of GEMM operand tensors (two-piece mode), handed out from zero-filled
     chunks; a slot lives as long as something references its view."""
 
-    CHUNK = 128
+    CHUNK = 256          # floats: 128 slots of two (max |t|, range statistic of the two-piece guard)
 
     def __init__(self):
         self.chunk, self.used = None, 0
@@ -225,8 +225,8 @@ class _MaxSlots:
                 self.held.append(self.chunk)
             self.chunk, self.used = torch.zeros(self.CHUNK, device=dev), 0      # a fill kernel (a memset node in a captured
                                                                                  # graph does not hold its place: btvae_slots_zero)
-        self.used += 1
-        return self.chunk[self.used - 1:self.used]
+        self.used += 2
+        return self.chunk[self.used - 2:self.used]
 
 
 MAX_SLOTS = _MaxSlots()
@@ -264,10 +264,81 @@ def measure_once(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def _operand_maxima(a: Optional[torch.Tensor], b: Optional[torch.Tensor]):
-    """Hand the next product its operands' maxima (both or nothing)."""
-    if a is not None and b is not None:
-        nv.lib().btvae_gemm_operand_maxima(P(a), P(b))
+class _Guard:
+    """Watch over the two-piece products.  Each product site (a Linear's forward, dX or weight-gradient product) has an
+    entry in a host-visible flag array the kernels write (``btvae_guard_flags``):
+
+    * *range*: an operand had a region more than 2^16 below its tensor's maximum (``btvae_guard_range_log2``) -- its
+      small values would keep an absolute, not a relative, error.  From the moment the host sees the flag, the site runs the three-piece kernel
+      (no maxima handed over); ``fallbacks`` counts such launches.  The flags are read without synchronising, so the
+      launch that raised one still ran on two pieces; with ``strict`` (``BTVAE_GUARD_STRICT=1``, or set by tests) the
+      test is made by a launch of its own and waited for before every product, at the price of a device sync each.
+    * *non-finite*: the accumulators of a two-piece product overflowed -- an operand maximum smaller than the data (a
+      stale slot) or data that is itself non-finite.  ``check()`` raises; it is called where the host synchronises
+      anyway (loss read-outs, validation, the benchmark's end)."""
+
+    def __init__(self):
+        self.ids: Dict[object, int] = {}
+        self._flags = None
+        self.fallbacks = 0
+        self.strict = os.environ.get("BTVAE_GUARD_STRICT", "0") == "1"
+        self.enabled = os.environ.get("BTVAE_GUARD", "1") != "0"       # 0: products are launched without a site (A/B timing)
+
+    def flags(self):
+        if self._flags is None:
+            import numpy as np
+            n = nv.lib().btvae_guard_sites()
+            ptr = nv.lib().btvae_guard_flags()
+            if not ptr:
+                raise RuntimeError("guard flags are not set up (btvae_init has not run on any device)")
+            self._flags = np.ctypeslib.as_array(ptr, shape=(2 * n,))
+        return self._flags
+
+    def site(self, key) -> int:
+        s = self.ids.get(key)
+        if s is None:
+            s = self.ids[key] = len(self.ids) % nv.lib().btvae_guard_sites()     # beyond the table sites share entries
+        return s
+
+    def tripped_sites(self) -> int:
+        return int((self.flags()[0::2] != 0).sum())
+
+    def check(self):
+        f = self.flags()
+        bad = (f[1::2] != 0).nonzero()[0]
+        if len(bad):
+            names = [k for k, v in self.ids.items() if v in set(bad.tolist())][:4]
+            f[1::2] = 0
+            raise RuntimeError(f"non-finite accumulators in a two-piece product (sites {names}): an operand's recorded maximum was "
+                               f"smaller than its data, or the data itself is not finite")
+
+    def reset(self):
+        self.flags()[:] = 0
+        self.fallbacks = 0
+
+
+GUARD = _Guard()
+
+
+def _operand_maxima(a: Optional[torch.Tensor], b: Optional[torch.Tensor], key=None):
+    """Hand the next product its operands' maxima (both or nothing) and its guard site; a site whose range flag is up
+    gets neither and runs on three exact pieces."""
+    if a is None or b is None:
+        return
+    L = nv.lib()
+    if key is None or not GUARD.enabled:
+        L.btvae_gemm_operand_maxima(P(a), P(b))
+        return
+    s = GUARD.site(key)
+    f = GUARD.flags()
+    if GUARD.strict and not f[2 * s] and not torch.cuda.is_current_stream_capturing():
+        nv.call("btvae_guard_check", P(a), P(b), s)
+        torch.cuda.current_stream().synchronize()
+    if f[2 * s]:
+        GUARD.fallbacks += 1
+        return
+    L.btvae_gemm_operand_maxima(P(a), P(b))
+    L.btvae_gemm_guard_site(s)
 
 
 def _planes_amax(planes: Optional[torch.Tensor], W: torch.Tensor) -> Optional[torch.Tensor]:
@@ -318,13 +389,13 @@ def _plan_planes(plan: "NetPlan", backward: bool) -> Dict[torch.nn.Linear, torch
     cnt = len(items)
     PtrArr, IntArr = nv.c_void_p * cnt, nv.ctypes.c_int * cnt
     if mode == 2:
-        maxima = torch.empty(cnt, device=buf.device)
+        maxima = torch.empty(2 * cnt, device=buf.device)      # two-float slots, cleared by the call itself
         for i, (lin, _) in enumerate(items):
-            out[lin]._btvae_amax = maxima[i:i + 1]
+            out[lin]._btvae_amax = maxima[2 * i:2 * i + 2]
         nv.call("btvae_weight_planes_f16_multi",
                 PtrArr(*[lin.weight.data_ptr() for lin, _ in items]), IntArr(*[lin.out_features for lin, _ in items]),
                 IntArr(*[lin.in_features for lin, _ in items]), PtrArr(*[out[lin].data_ptr() for lin, _ in items]),
-                IntArr(*[w for _, w in items]), PtrArr(*[maxima[i:i + 1].data_ptr() for i in range(cnt)]), cnt)
+                IntArr(*[w for _, w in items]), PtrArr(*[maxima[2 * i:2 * i + 2].data_ptr() for i in range(cnt)]), cnt)
         return out
     nv.call("btvae_weight_planes_multi",
             PtrArr(*[lin.weight.data_ptr() for lin, _ in items]), IntArr(*[lin.out_features for lin, _ in items]),
@@ -431,7 +502,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         tiles = (M + 127) // 128
         y = _rows_on_lines(M, N, dev)
         part = WS.get("bnpart", tiles * 2 * N, dev)
-        _operand_maxima(_amax(x), _planes_amax(wp, W))
+        _operand_maxima(_amax(x), _planes_amax(wp, W), (id(u.lin.weight), "fwd"))
         _track_output(y)
         _pitches(n=y)
         nv.call("btvae_linear_relu_stats_fwd_pw", PR(x), x.stride(0), P(W), P(wp), P(b), PR(y), P(part), M, K, N)
@@ -471,7 +542,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
     elif u.bn is None and train:
         # unit built without BatchNorm: y = relu(x W^T + b) is what the backward needs; dropout / residual on top
         y = _rows_on_lines(M, N, dev)
-        _operand_maxima(_amax(x), _planes_amax(wp, W))
+        _operand_maxima(_amax(x), _planes_amax(wp, W), (id(u.lin.weight), "fwd"))
         _track_output(y)
         nv.call("btvae_linear_relu_affine_fwd_pw_ld", PR(x), x.stride(0), P(W), P(wp), P(b), None, None, None, 0, PR(y), y.stride(0), M, K, N)
         keep, ks = None, 1.0
@@ -493,7 +564,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         if u.bn is not None:
             scale, shift = torch.empty(N, device=dev), torch.empty(N, device=dev)
             nv.call("btvae_bn_fold_eval", P(u.bn.weight), P(u.bn.bias), P(u.bn.running_mean), P(u.bn.running_var), float(u.bn.eps), P(scale), P(shift), N)
-        _operand_maxima(_amax(x), _planes_amax(wp, W))
+        _operand_maxima(_amax(x), _planes_amax(wp, W), (id(u.lin.weight), "fwd"))
         _track_output(out)
         nv.call("btvae_linear_relu_affine_fwd_pw_ld", PR(x), x.stride(0), P(W), P(wp), P(b), P(scale), P(shift),
                 PR(x) if u.residual else None, x.stride(0), PR(out), out.stride(0), M, K, N)
@@ -519,7 +590,7 @@ def head_forward(u: Unit, x, act: int, lo: float, hi: float, want_dfac: bool, wa
     sq = torch.empty(M, N, device=dev) if want_sq else None
     ws = WS.get("headslab", HEAD_WS_FLOATS, dev) if M <= 128 * 128 else None      # few row tiles: split reduction (see the C side)
     if N > 64 and ws is None:                 # the 128-wide head kernel has a two-piece form; the narrow one (N <= 64) is
-        _operand_maxima(_amax(a), _amax(W))   # memory-bound and the split-reduction one latency-bound
+        _operand_maxima(_amax(a), _amax(W), (id(u.lin.weight), "fwd"))   # memory-bound and the split-reduction one latency-bound
     nv.call("btvae_linear_head_fwd_ws", PR(a), a.stride(0), P(W), P(b), act, float(lo), float(hi), P(val), P(dfac), P(sq),
             P(ws), ws.numel() if ws is not None else 0, M, K, N)
     own = planes.get(u.lin) if planes else None
@@ -586,7 +657,7 @@ def _wgrad(lin: torch.nn.Linear, dy: torch.Tensor, x: torch.Tensor, x_scale, x_s
     M, N = dy.shape
     K = x.shape[1]
     ws = WS.get("wgrad", WGRAD_WS_FLOATS, dy.device)
-    _operand_maxima(_amax(dy), _amax(x))
+    _operand_maxima(_amax(dy), _amax(x), (id(lin.weight), "wgrad"))
     _pitches(n=dy)
     if x_scale is None:
         nv.call("btvae_linear_wgrad", PR(dy), PR(x), x.stride(0), P(_grad_view(lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
@@ -625,7 +696,7 @@ def _dgrad_with_producer_backward(pr: BwdProducts, dy: torch.Tensor, W: torch.Te
     dpre = _rows_like(sv_p.y)
     part = WS.get("bnbwd_part", tiles * Np, dev)
     r = _like_rows(r, dpre)
-    _operand_maxima(_amax(dy), _planes_amax(planes, W))
+    _operand_maxima(_amax(dy), _planes_amax(planes, W), (id(W), "dgrad"))
     _track_output(dpre)
     _pitches(n=dy, k=dpre, same_k=(r, sv_p.y))
     nv.call("btvae_linear_dgrad_bnbwd_pw", PR(dy), P(W), P(planes), PR(r), PR(sv_p.y), P(sv_p.mean), P(sv_p.invstd), P(u_p.bn.weight), P(sums),
@@ -720,12 +791,12 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
             and src.out_products is None and K % 4 == 0):
         tiles = (M + 127) // 128
         part = torch.empty(tiles, 2, K, device=dev)
-        _operand_maxima(_amax(dpre), _planes_amax(sv.w_planes, u.lin.weight))
+        _operand_maxima(_amax(dpre), _planes_amax(sv.w_planes, u.lin.weight), (id(u.lin.weight), "dgrad"))
         _pitches(n=dpre, k=dx, same_k=(r, src.y))
         nv.call("btvae_linear_dgrad_gstats_pw", PR(dpre), P(u.lin.weight), P(sv.w_planes), PR(r), PR(src.y), P(src.mean), P(src.invstd), PR(dx), P(part), M, N, K)
         src.g_partials = (part, tiles)
     else:
-        _operand_maxima(_amax(dpre), _planes_amax(sv.w_planes, u.lin.weight))
+        _operand_maxima(_amax(dpre), _planes_amax(sv.w_planes, u.lin.weight), (id(u.lin.weight), "dgrad"))
         _pitches(n=dpre)
         nv.call("btvae_linear_dgrad_pw", PR(dpre), P(u.lin.weight), P(sv.w_planes), PR(r), PR(dx), dx.stride(0), M, N, K)
     return dx
@@ -753,7 +824,7 @@ def net_backward(plan: NetPlan, tape: NetTape, draw: Dict[str, torch.Tensor], ne
             g = _dgrad_with_producer_backward(x_pr, d, last.lin.weight, None, accumulate, tape.head_planes.get(name))
         else:
             g = _rows_like(t_in)
-            _operand_maxima(_amax(d), _planes_amax(tape.head_planes.get(name), last.lin.weight))
+            _operand_maxima(_amax(d), _planes_amax(tape.head_planes.get(name), last.lin.weight), (id(last.lin.weight), "dgrad"))
             nv.call("btvae_linear_dgrad_pw", P(d), P(last.lin.weight), P(tape.head_planes.get(name)), None, PR(g), g.stride(0), M, N, K)
         svs = tape.heads[name]
         for i in range(len(units) - 2, -1, -1):

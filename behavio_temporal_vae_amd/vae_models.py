@@ -583,6 +583,13 @@ class VAE(torch.nn.Module):
         if key is not None:
             graphs = self.__dict__.setdefault("_step_graphs", {})
             seen = self.__dict__.setdefault("_step_seen", {})
+            # a captured step has its products' kernels baked in: once the two-piece guard raises a range flag, what was
+            # captured before no longer matches what the engine would launch (that site on three pieces)
+            tripped = E.GUARD.tripped_sites() if self.gemm_precision == "fp32_split2" else 0
+            if tripped != self.__dict__.get("_step_graph_tripped", 0):
+                graphs.clear()
+                seen.clear()
+                self.__dict__["_step_graph_tripped"] = tripped
             g = graphs.get(key)
             if g is None and seen.get(key, 0) >= STEP_GRAPH_WARMUP and not self.__dict__.get("_step_graph_failed"):
                 self._check_arena()
@@ -640,6 +647,7 @@ class VAE(torch.nn.Module):
         msg = (f"Iteration: {itx} -- ELBO={loss_dict['elbo'].item():.4e} / RLL={loss_dict['rll'].item():.4e} / "
                f"KL={loss_dict['kl'].item():.4e}")
         (pbar.write if pbar is not None else print)(msg)
+        E.GUARD.check()          # the read-outs above synchronised: what the two-piece guard recorded is final
 
     def move_to_device(self, inputs, device="cpu"):
         return inputs.to(device)

@@ -47,14 +47,38 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X fp32 matrix peak (v_mfma_f32_32x32x2_f
 BREAKDOWN_STEPS = 3             # untimed steps with every launch event-timed, for the per-family table
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X bf16 dense matrix peak (v_mfma_f32_32x32x16_bf16, 1024 FLOP/clk/SIMD)
 SPLIT_TERMS = 6                  # bf16 MFMAs issued per fp32 product in the split mode
-# HBM-side bytes of one launch of the dominant kernel (M=65536, N=K=1000) from PMC passes kept under profiles/
-DOMINANT_KERNEL_HBM_BYTES = {"fp32": 2 * 324658 * 1024 + 304764 * 1024, "fp32_split": 2 * 505912 * 1024 + 258478 * 1024,
-                             "fp32_split2": 2 * 387867 * 1024 + 292795 * 1024}       # inside the training leg, line-aligned rows
 
 
-# the same for the eval-mode hidden Linear (relu + affine epilogue) in the two-piece mode at the shapes the scoring and
-# imputation legs run by default: {rows M: bytes} (profiles/r2b_gemm_two_piece_pmc.md)
-EVAL_KERNEL_HBM_BYTES = {819200: 2 * 4987133 * 1024 + 3456003 * 1024, 25000: 2 * 151171 * 1024 + 105498 * 1024}
+def kernel_sources_hash() -> str:
+    """sha256 over the kernel sources: what a recorded PMC figure was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "behavio_temporal_vae_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def recorded_traffic(leg: str, precision: str, M: int):
+    """Beyond-L2 bytes per launch of a leg's dominant kernel from the PMC passes recorded in profiles/traffic.json
+    (``tools/profiling/traffic_json.py``: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over this script, FETCH_SIZE
+    doubled as gfx950 needs), together with where they come from.  The figures are not collected live, so they are only
+    reported when the kernel sources still hash to what they were measured on; otherwise ``traffic`` is null and the
+    note says so."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None, "no profiles/traffic.json"
+    entry = rec.get("legs", {}).get(f"{leg}:{precision}:{M}")
+    if entry is None:
+        return None, f"profiles/traffic.json holds no pass for {leg} / {precision} / M={M}"
+    src = f"profiles/traffic.json ({rec.get('command', '?')}; commit {rec.get('commit', '?')}): FETCH_SIZE x2 {entry['fetch_x2_bytes']:.0f} + WRITE_SIZE {entry['write_bytes']:.0f} bytes, median per dispatch"
+    if rec.get("kernel_sources_hash") != kernel_sources_hash():
+        return None, "stale: kernel sources changed since " + src
+    return entry["fetch_x2_bytes"] + entry["write_bytes"], src
 
 
 KERNEL_NAME = {"fp32_split": "gemm_split_mfma", "fp32_split2": "gemm_split_mfma", "fp32": "gemm_f32_mfma", "bf16": "gemm_bf16_mfma"}
@@ -183,6 +207,16 @@ def cpu_scoring_baseline(K=1000, N=32):
             "sample": f"{N} profiles at K={K} in one call after a warm-up call on {N // 4}, {dt:.2f} s"}
 
 
+def guard_report():
+    """What the guard of the two-piece products saw over the whole run (every leg): launches routed to the three-piece
+    kernel because an operand had a region far below its maximum, sites that raised that flag, and -- raising -- any
+    product whose accumulators overflowed."""
+    from behavio_temporal_vae_amd import engine as E
+    E.GUARD.check()
+    return {"fallbacks": int(E.GUARD.fallbacks), "sites_flagged": E.GUARD.tripped_sites(), "nonfinite": 0,
+            "note": "fallbacks must be 0 on the headline run: every Linear product of the timed steps ran on two fp16 pieces"}
+
+
 def _peak(precision):
     if precision == "fp32_split":
         return PEAK_BF16_MFMA_TFLOPS / SPLIT_TERMS, "fp32-equivalent FLOP/s: bf16 dense peak 2500 / 6 bf16 MFMAs per fp32 product"
@@ -191,7 +225,7 @@ def _peak(precision):
     return (PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_BF16_MFMA_TFLOPS), "dense matrix peak of the operand type"
 
 
-def _dominant_roofline(nv, precision, what, M, algorithmic_bytes):
+def _dominant_roofline(nv, precision, what, M, algorithmic_bytes, leg):
     """Roofline block of the launches of the gemm_fwd family with the largest FLOP count, from the HIP events recorded
     since ``prof_enable`` (call after a device sync)."""
     dom_ms, dom_fl, dom_n = nv.prof_dominant("gemm_fwd")
@@ -201,9 +235,7 @@ def _dominant_roofline(nv, precision, what, M, algorithmic_bytes):
     achieved = dom_fl * dom_n / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     return {"bound": "mfma", "kernel": what, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "peak_note": note, "flops_per_launch": dom_fl, "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
-            "traffic": EVAL_KERNEL_HBM_BYTES.get(M) if precision == "fp32_split2" else None,
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this kernel at this shape, separate passes over this "
-                              "leg (profiles/r2b_gemm_two_piece_pmc.md); not collected live",
+            "traffic": recorded_traffic(leg, precision, M)[0], "traffic_source": recorded_traffic(leg, precision, M)[1],
             "algorithmic_bytes": algorithmic_bytes}
 
 
@@ -241,7 +273,7 @@ def scoring_benchmark(dev, rank, world, n_profiles, K, chunk):
     dt = time.perf_counter() - t0
     roof = _dominant_roofline(nv, model.gemm_precision,
                               f"{KERNEL_NAME[model.gemm_precision]}<k-contig,k-contig,relu+affine(+residual),pre-split weight> M={M} N=K=1000 "
-                              "(decoder hidden Linear, eval mode)", M, 4.0 * (2.0 * M * 1000 + 1000 * 1000))
+                              "(decoder hidden Linear, eval mode)", M, 4.0 * (2.0 * M * 1000 + 1000 * 1000), "scoring_fwd")
     nv.prof_filter(None, 0.0)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -292,7 +324,7 @@ def imputation_benchmark(dev, rows, sweeps):
         dt = time.perf_counter() - t0
     roof = _dominant_roofline(nv, model.gemm_precision,
                               f"{KERNEL_NAME[model.gemm_precision]}<k-contig,k-contig,relu+affine(+residual),pre-split weight> M={rows} N=K=1000 "
-                              "(hidden Linear, eval mode)", rows, 4.0 * (2.0 * rows * 1000 + 1000 * 1000))
+                              "(hidden Linear, eval mode)", rows, 4.0 * (2.0 * rows * 1000 + 1000 * 1000), "imputation_fwd")
     nv.prof_filter(None, 0.0)
     flops = (5_148_000 + 5_200_000) * 2.0 * rows * sweeps
     return {"metric": "pseudo-Gibbs imputation profile-sweeps/sec", "value": rows * sweeps / dt, "unit": "profile-sweeps/s",
@@ -629,8 +661,8 @@ def main():
                          "flops_per_launch": dom_fl, "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
                          "measured_in": ("5 eager steps right after the timed region (the timed steps are replayed from a HIP graph)" if graphed
                                          else "the timed region"),
-                         "traffic": DOMINANT_KERNEL_HBM_BYTES.get(main_precision) if (S * B == 65536) else None,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this kernel at this shape, separate passes: profiles/r2b_gemm_two_piece_pmc.md (fp32_split2), profiles/r1_gemm_fwd_pmc.md (other modes); not collected live",
+                         "traffic": recorded_traffic("training_fwd", main_precision, S * B)[0],
+                         "traffic_source": recorded_traffic("training_fwd", main_precision, S * B)[1],
                          "algorithmic_bytes": 4.0 * (S * B * 1000 + 1000 * 1000 + S * B * 1000),
                          "limiter_note": ("fp32_split2: with every MFMA removed this kernel takes 0.397 ms instead of 0.408 at the full clock: "
                                           "its time is set by the global-memory path (activations re-read 8x and the weight image swept from L2, "
@@ -639,6 +671,7 @@ def main():
                          "all_gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None,
                          "step_model_tflops": flops_per_sample(S) * B / (ms_step * 1e-3) / 1e12,
                          "step_frac_of_fp32_mfma_peak": flops_per_sample(S) * B / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+            "two_piece_guard": guard_report(),
             "kernels": kernels,
             "kernels_note": f"per kernel family, HIP events around every launch of {BREAKDOWN_STEPS} extra steps after the timed region",
             "last_loss": last,

@@ -58,7 +58,10 @@ int btvae_weight_planes_multi(const float* const* W, const int* N, const int* K,
                               int count, void* stream);
 
 /* Mode 3 (no counterpart in the reference: torch.nn.Linear multiplies fp32 values, src/submodels.py:15-17).
- * btvae_absmax folds max|x| over n floats into the device scalar *out, which must hold zero or a maximum to extend;
+ * A maximum "slot" is TWO floats in device memory: [0] = max |x|, [1] = a range statistic the same kernels maintain for the
+ * guard below (the largest of 0x7f800000 - bits(m) over the regional maxima m > 0 of the waves / workgroups that wrote
+ * the tensor); both start at zero.  Every amax / amax_out pointer below points at such a pair.
+ * btvae_absmax folds max|x| over n floats into the slot *out, which must hold zeros or a maximum to extend;
  * btvae_slots_zero clears n neighbouring slots with a kernel launch (use it rather than hipMemsetAsync on a stream that may
  * be under capture: a memset node was seen not to keep its place among a graph's kernel nodes).
  * btvae_gemm_operand_maxima names the device scalars holding the maxima of the A operand (activations or gradients)
@@ -74,7 +77,23 @@ int btvae_weight_planes_multi(const float* const* W, const int* N, const int* K,
  * btvae_reparam_kl_fwd) to fold max|Y / Out / dPre / Wf / zc| into *amax_out as btvae_absmax would, without a pass of
  * its own. */
 int btvae_absmax(const float* x, long long n, float* out, void* stream);
+/* n floats (two per slot) */
 int btvae_slots_zero(float* slots, int n, void* stream);
+/* Guard of the mode-3 products (no counterpart in the reference).  Two scaled fp16 pieces represent an element to ~2^-23
+ * of its magnitude only while it is within ~2^17 of its tensor's maximum, and a maximum that understates the data
+ * overflows fp16.  A product launched after btvae_gemm_guard_site(s) (consumed by that launch; -1 = none) records in the
+ * host-visible array btvae_guard_flags() (2 * btvae_guard_sites() ints in mapped host memory, set up by the first
+ * btvae_init; NULL before): [2 s] = 1 when an operand's slot shows a region more than 2^16 below the tensor's maximum
+ * (btvae_guard_range_log2 sets another threshold, process-wide; a region that far down holds elements ~2^19 below the
+ * maximum, still represented to ~2^-21 of their magnitude) -- run that product without maxima (three exact pieces) from
+ * then on; [2 s + 1] = 1 when its accumulators came out non-finite -- an error.  What the host reads is final for
+ * launches that have completed; it clears what it has handled.  btvae_guard_check makes the range test as a launch of
+ * its own (for callers that synchronise and decide before they launch the product). */
+int btvae_guard_sites(void);
+int btvae_guard_range_log2(int log2_range);
+int* btvae_guard_flags(void);
+int btvae_gemm_guard_site(int site);
+int btvae_guard_check(const float* amax_a, const float* amax_b, int site, void* stream);
 int btvae_output_maximum(float* amax_out);
 int btvae_gemm_operand_maxima(const float* amax_a, const float* amax_b);
 int btvae_weight_planes_f16(const float* W, int ldw, int N, int K, void* planes, int which, const float* amax, void* stream);

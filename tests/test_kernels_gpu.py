@@ -404,7 +404,8 @@ def test_presplit_weight_products(dev, gemm_mode, M, N, K):
 
 
 def absmax_of(t):
-    out = torch.zeros(1, device=t.device)
+    """A maximum slot (two floats: max |t| and the range statistic of the two-piece guard) filled by ``btvae_absmax``."""
+    out = torch.zeros(2, device=t.device)
     nv.call("btvae_absmax", P(t), t.numel(), P(out))
     return out
 
@@ -415,12 +416,12 @@ def test_absmax(dev, n):
     x[n // 2] = -7.5
     for view in (x[:n], x[1:n + 1]):                 # 16-byte aligned and not
         got = absmax_of(view.contiguous() if view.data_ptr() % 16 == 0 else view)
-        assert got.item() == view.abs().max().item()
-    keep = torch.full((1,), 100.0, device=dev)       # extends a maximum already in the slot
+        assert got[0].item() == view.abs().max().item()
+    keep = torch.tensor([100.0, 0.0], device=dev)    # extends a maximum already in the slot
     nv.call("btvae_absmax", P(x[:n]), n, P(keep))
-    assert keep.item() == 100.0
+    assert keep[0].item() == 100.0
     z = torch.zeros(8, device=dev)
-    assert absmax_of(z).item() == 0.0
+    assert absmax_of(z).tolist() == [0.0, 0.0]
 
 
 @pytest.fixture
@@ -542,28 +543,28 @@ def test_output_maximum_from_producers(dev, gemm_mode, M, N, K):
     X, W, b = rnd(M, K, seed=91).float().to(dev), rnd(N, K, seed=92, scale=0.2).float().to(dev), rnd(N, seed=93, scale=0.1).float().to(dev)
     tiles = (M + 127) // 128
     Y, part = torch.empty(M, N, device=dev), torch.empty(tiles, 2, N, device=dev)
-    slot = torch.zeros(1, device=dev)
+    slot = torch.zeros(2, device=dev)
     L.btvae_output_maximum(P(slot))
     nv.call("btvae_linear_relu_stats_fwd", P(X), K, P(W), P(b), P(Y), P(part), M, K, N)
-    assert slot.item() == Y.abs().max().item() > 0
-    slot.fill_(1e6)
+    assert slot[0].item() == Y.abs().max().item() > 0
+    slot[0] = 1e6
     L.btvae_output_maximum(P(slot))
     nv.call("btvae_linear_relu_stats_fwd", P(X), K, P(W), P(b), P(Y), P(part), M, K, N)
-    assert slot.item() == 1e6
+    assert slot[0].item() == 1e6
     nv.call("btvae_linear_relu_stats_fwd", P(X), K, P(W), P(b), P(Y), P(part), M, K, N)      # no request pending
-    assert slot.item() == 1e6
+    assert slot[0].item() == 1e6
     sc, sh, R = rnd(N, seed=94).float().to(dev), rnd(N, seed=95).float().to(dev), rnd(M, N, seed=96).float().to(dev)
     out = torch.empty(M, N, device=dev)
     slot.zero_()
     L.btvae_output_maximum(P(slot))
     nv.call("btvae_linear_relu_affine_fwd", P(X), K, P(W), P(b), P(sc), P(sh), P(R), P(out), M, K, N)
-    assert slot.item() == out.abs().max().item()
+    assert slot[0].item() == out.abs().max().item()
     mean, inv = Y.mean(0), 1 / torch.sqrt(Y.var(0, unbiased=False) + 1e-5)
     gam, bet = (1 + 0.3 * rnd(N, seed=97)).float().to(dev), rnd(N, seed=98).float().to(dev)
     slot.zero_()
     L.btvae_output_maximum(P(slot))
     nv.call("btvae_bn_apply_fwd", P(Y), P(mean), P(inv), P(gam), P(bet), P(R), None, 1.0, P(out), M, N)
-    assert slot.item() == out.abs().max().item()
+    assert slot[0].item() == out.abs().max().item()
     G = rnd(M, N, seed=99).float().to(dev)
     dpre = torch.empty(M, N, device=dev)
     scr = torch.empty(L.btvae_bn_relu_bwd_scratch(M, N), device=dev)
@@ -571,11 +572,11 @@ def test_output_maximum_from_producers(dev, gemm_mode, M, N, K):
     slot.zero_()
     L.btvae_output_maximum(P(slot))
     nv.call("btvae_bn_relu_bwd", P(G), P(Y), P(mean), P(inv), P(gam), None, 1.0, P(dg), P(dbt), P(dbi), None, P(dpre), P(scr), M, N, 0)
-    assert slot.item() == dpre.abs().max().item()
+    assert slot[0].item() == dpre.abs().max().item()
     slot.zero_()
     L.btvae_output_maximum(P(slot))
     nv.call("btvae_relu_bwd", P(G), P(Y), None, 1.0, P(dbi), None, P(dpre), P(scr), M, N, 0)
-    assert slot.item() == dpre.abs().max().item()
+    assert slot[0].item() == dpre.abs().max().item()
     if N % 4 == 0:
         dY = rnd(M, K, seed=100).float().to(dev)          # dX product of a Linear [K out, N in]: G = dY Wt, Wt [K, N]
         Wt = rnd(K, N, seed=101, scale=0.2).float().to(dev)
@@ -584,7 +585,7 @@ def test_output_maximum_from_producers(dev, gemm_mode, M, N, K):
         slot.zero_()
         L.btvae_output_maximum(P(slot))
         nv.call("btvae_linear_dgrad_bnbwd", P(dY), P(Wt), None, P(Y), P(mean), P(inv), P(gam), P(sums), M, P(dpre), P(cp), M, K, N)
-        assert slot.item() == dpre.abs().max().item()
+        assert slot[0].item() == dpre.abs().max().item()
     # folded weights and the decoder's z|c rows
     Wf, bf2, scd, shd = torch.empty(N, K, device=dev), torch.empty(N, device=dev), torch.empty(K, device=dev), torch.empty(K, device=dev)
     mk, ik = X.mean(0), 1 / torch.sqrt(X.var(0, unbiased=False) + 1e-5)
@@ -592,7 +593,7 @@ def test_output_maximum_from_producers(dev, gemm_mode, M, N, K):
     slot.zero_()
     L.btvae_output_maximum(P(slot))
     nv.call("btvae_bn_fold_linear", P(W), P(b), P(mk), P(ik), P(gk), P(bk), P(Wf), P(bf2), P(scd), P(shd), N, K)
-    assert slot.item() == Wf.abs().max().item() > 0
+    assert slot[0].item() == Wf.abs().max().item() > 0
     R_, S_, Ld, Cd = 37, 3, 10, 4
     mu, sg = rnd(R_, Ld, seed=105).float().to(dev), (0.1 + rnd(R_, Ld, seed=106).abs()).float().to(dev)
     ep, cd = rnd(S_ * R_, Ld, seed=107).float().to(dev), (5 * rnd(R_, Cd, seed=108)).float().to(dev)
@@ -600,14 +601,14 @@ def test_output_maximum_from_producers(dev, gemm_mode, M, N, K):
     slot.zero_()
     L.btvae_output_maximum(P(slot))
     nv.call("btvae_reparam_kl_fwd", P(mu), P(sg), P(ep), None, P(cd), P(zc), P(kl), R_, S_, Ld, Cd, R_, 0, Cd, 0, 0)
-    assert slot.item() == zc.abs().max().item() > 0
+    assert slot[0].item() == zc.abs().max().item() > 0
     # a product that is no producer drops the request
     L.btvae_output_maximum(P(slot))
     D = torch.empty(M, K, device=dev)
     nv.call("btvae_linear_dgrad", P(Y), P(W), None, P(D), K, M, N, K)
-    before = slot.item()
+    before = slot[0].item()
     nv.call("btvae_linear_relu_stats_fwd", P(X), K, P(W), P(b), P(Y), P(part), M, K, N)
-    assert slot.item() == before
+    assert slot[0].item() == before
 
 
 def test_weight_planes_batch(dev):
@@ -641,18 +642,18 @@ def test_weight_planes_f16_batch(dev):
     sizes = [L.btvae_weight_planes_elems(n, k) for n, k in shapes]
     one = [torch.full((s,), 0x7FC0, dtype=torch.int16, device=dev) for s in sizes]
     many = [torch.full((s,), 0x7FC0, dtype=torch.int16, device=dev) for s in sizes]
-    slots = torch.full((64,), 123.0, device=dev)
+    slots = torch.full((128,), 123.0, device=dev)                               # 64 two-float slots
     where = list(range(12)) + [20, 40, 41, 42, 50, 13, 14, 63]                  # runs of neighbours and loners
     for W, (n, k), pl, wh in zip(Ws, shapes, one, which):
         nv.call("btvae_weight_planes_f16", P(W), k, n, k, P(pl), wh, P(absmax_of(W)))
     cnt = len(shapes)
     PA, IA = ctypes.c_void_p * cnt, ctypes.c_int * cnt
     nv.call("btvae_weight_planes_f16_multi", PA(*[W.data_ptr() for W in Ws]), IA(*[n for n, _ in shapes]), IA(*[k for _, k in shapes]),
-            PA(*[pl.data_ptr() for pl in many]), IA(*which), PA(*[slots[w:w + 1].data_ptr() for w in where]), cnt)
+            PA(*[pl.data_ptr() for pl in many]), IA(*which), PA(*[slots[2 * w:2 * w + 2].data_ptr() for w in where]), cnt)
     for i, (a, b) in enumerate(zip(one, many)):
         assert torch.equal(a, b), f"entry {i}"
-        assert slots[where[i]].item() == Ws[i].abs().max().item(), f"maximum {i}"
-    untouched = [i for i in range(64) if i not in where]
+        assert slots[2 * where[i]].item() == Ws[i].abs().max().item(), f"maximum {i}"
+    untouched = [j for i in range(64) if i not in where for j in (2 * i, 2 * i + 1)]
     assert bool((slots[untouched] == 123.0).all())
 
 
@@ -665,11 +666,11 @@ def test_weight_maxima_retaken_by_every_graph_replay(dev):
     Ws = [rnd(n, k, seed=170 + i).float().to(dev) for i, (n, k) in enumerate(shapes)]
     L = nv.lib()
     planes = [torch.zeros(L.btvae_weight_planes_elems(n, k), dtype=torch.int16, device=dev) for n, k in shapes]
-    slots = torch.full((8,), 5.0e4, device=dev)
+    slots = torch.full((16,), 5.0e4, device=dev)                                # eight two-float slots
     cnt = len(shapes)
     PA, IA = ctypes.c_void_p * cnt, ctypes.c_int * cnt
     args = (PA(*[W.data_ptr() for W in Ws]), IA(*[n for n, _ in shapes]), IA(*[k for _, k in shapes]),
-            PA(*[pl.data_ptr() for pl in planes]), IA(3, 3, 2), PA(slots[1:2].data_ptr(), slots[2:3].data_ptr(), slots[6:7].data_ptr()), cnt)
+            PA(*[pl.data_ptr() for pl in planes]), IA(3, 3, 2), PA(slots[2:4].data_ptr(), slots[4:6].data_ptr(), slots[12:14].data_ptr()), cnt)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -684,13 +685,59 @@ def test_weight_maxima_retaken_by_every_graph_replay(dev):
         graph.replay()
         got = slots.cpu()
         for i, j in enumerate((1, 2, 6)):
-            assert got[j].item() == Ws[i].abs().max().item(), (factor, i)
-        assert bool((got[[0, 3, 4, 5, 7]] == 5.0e4).all())
+            assert got[2 * j].item() == Ws[i].abs().max().item(), (factor, i)
+        assert bool((got[[0, 1, 6, 7, 8, 9, 10, 11, 14, 15]] == 5.0e4).all())
         one = torch.zeros_like(planes[1])
-        nv.call("btvae_weight_planes_f16", P(Ws[1]), 1000, 1000, 1000, P(one), 3, P(slots[2:3]))
+        nv.call("btvae_weight_planes_f16", P(Ws[1]), 1000, 1000, 1000, P(one), 3, P(slots[4:6]))
         assert torch.equal(one, planes[1]), factor
-    nv.call("btvae_slots_zero", P(slots[2:]), 5)
-    assert slots.cpu().tolist()[2:7] == [0.0] * 5 and slots[1].item() > 0 and slots[7].item() == 5.0e4
+    nv.call("btvae_slots_zero", P(slots[4:]), 5)
+    assert slots.cpu().tolist()[4:9] == [0.0] * 5 and slots[2].item() > 0 and slots[9].item() == 5.0e4
+
+
+def test_two_piece_guard_flags(dev, two_piece):
+    """The guard of the two-piece products: a product launched for a site records, in the host-visible flag array,
+    (a) an operand with a region more than 2^16 (the default threshold) below its tensor's maximum -- a planted outlier, or a recorded maximum
+    far above the data -- and (b) non-finite accumulators, which is what a recorded maximum below the data produces
+    (fp16 overflow; the ReLU epilogue would turn the NaNs into zeros without a trace).  Clean operands raise nothing."""
+    import numpy as np
+    L = nv.lib()
+    flags = np.ctypeslib.as_array(L.btvae_guard_flags(), shape=(2 * L.btvae_guard_sites(),))
+    M, K, N = 512, 1000, 256
+    X, W = rnd(M, K, seed=180).float().to(dev), rnd(N, K, seed=181, scale=0.2).float().to(dev)
+    bd = torch.zeros(N, device=dev)
+    Y, part = torch.empty(M, N, device=dev), torch.empty((M + 127) // 128, 2, N, device=dev)
+    ref = torch.relu(X.double() @ W.double().t())
+
+    def product(xslot, wslot, site, x=X):
+        flags[2 * site:2 * site + 2] = 0
+        L.btvae_gemm_operand_maxima(P(xslot), P(wslot))
+        L.btvae_gemm_guard_site(site)
+        nv.call("btvae_linear_relu_stats_fwd", P(x), K, P(W), P(bd), P(Y), P(part), M, K, N)
+        torch.cuda.synchronize()
+        return int(flags[2 * site]), int(flags[2 * site + 1])
+
+    mw = absmax_of(W)
+    assert product(absmax_of(X), mw, 7) == (0, 0)
+    assert float((Y.double() - ref).abs().max()) <= 1e-4
+    Xo = X.clone()
+    Xo[300, 17] = 2.0 ** 20                                   # one element far above everything else
+    assert product(absmax_of(Xo), mw, 8, Xo) == (1, 0)
+    big = absmax_of(X)
+    big[0] *= 2.0 ** 18                                       # a recorded maximum far above the data (a stale slot)
+    assert product(big, mw, 9) == (1, 0)
+    small = absmax_of(X)
+    small[0] *= 2.0 ** -9                                     # ... and one far below it: fp16 overflow
+    assert product(small, mw, 10) == (0, 1)
+    assert flags[14] == 0 and flags[15] == 0                  # untouched site
+    # the launch-of-its-own form of the range test
+    flags[22:24] = 0
+    nv.call("btvae_guard_check", P(absmax_of(Xo)), P(mw), 11)
+    torch.cuda.synchronize()
+    assert flags[22] == 1
+    nv.call("btvae_guard_check", P(absmax_of(X)), P(mw), 12)
+    torch.cuda.synchronize()
+    assert flags[24] == 0
+    flags[:] = 0
 
 
 def test_matmul_bias_and_mul(dev):

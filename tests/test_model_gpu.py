@@ -774,6 +774,9 @@ def test_config0_full_size_step_vs_oracle(dev, precision):
         errs.append((float((p.grad.double().cpu() - ref).norm() / ref.norm()), k))
     errs.sort(reverse=True)
     assert errs[0][0] <= 6e-3, errs[:5]
+    # the square hidden-layer weights: large-norm sums rather than cancellations, held to a third of that
+    big = [(e, k) for e, k in errs if k.endswith(".weight") and tuple(dict(m.named_parameters())[k].shape) == (1000, 1000)]
+    assert len(big) == 10 and max(big)[0] <= 2e-3, sorted(big, reverse=True)[:4]
     m._flush_bn_counters()
     sd = m.state_dict()
     for k, ref in o["after"].items():
@@ -782,3 +785,82 @@ def test_config0_full_size_step_vs_oracle(dev, precision):
             assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-7, k
         elif "num_batches_tracked" in k:
             assert int(sd[k]) == int(ref), k
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_two_piece_guard_in_a_training_step(dev, strict):
+    """A config0-shaped step (H = 1000) in which one profile is 2^20 times the others: the encoder's input, every hidden
+    activation behind it (its row dominates) and the head gradients then have regions far below their tensors' maxima,
+    where two scaled fp16 pieces keep only an absolute error.  With the guard waited for (strict) the affected products
+    run on three exact pieces from the first launch on and the step meets the fp64 oracle at 1e-4; without waiting, the
+    first step raises the flags and the second one falls back."""
+    import contextlib, io
+    from oracle import refimpl as R
+    from behavio_temporal_vae_amd.vae_models import CVAE
+    from behavio_temporal_vae_amd import engine as E
+    g = load_golden("config0_sgd_steps")
+    cfg = json.loads(str(g["model_cfg"]))
+    B, S, D, C, L = 256, 4, 48, 4, 48
+    torch.manual_seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = CVAE(input_dim=D, conditioner=Cdim(C), **cfg)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    gen = torch.Generator().manual_seed(78)
+    x = torch.randn(B, D, generator=gen).add_(1.0).clamp_(-3, 5)
+    x[0] *= 2.0 ** 20
+    ang = torch.rand(B, 2, generator=gen) * (2 * np.pi)
+    c = torch.cat([torch.cos(ang), torch.sin(ang)], 1)
+    eps = torch.randn(S, B, L, generator=gen)
+    spec = R.model_spec(D, C, cfg)
+    sd64 = R.cast_state({k: v.clone() for k, v in sd0.items()}, torch.float64)
+    terms, grads, norm = R.train_step(sd64, spec, None, x.double(), c.double(), eps.double(), lr=0.0, weight_decay=0.0, beta=1.0,
+                                      max_norm=1.0, optimizer="sgd")
+    m = m.to(dev).train()
+    assert m.gemm_precision == "fp32_split2"
+    E.GUARD.reset()
+    was = E.GUARD.strict
+    E.GUARD.strict = strict
+    try:
+        xd, cd, ed = x.to(dev), c.to(dev), eps.to(dev)
+        fw = m._run_forward(xd, cd, S, eps=ed, tape=True)
+        out = m._loss_and_backward(fw, xd, 1.0).tolist()
+        torch.cuda.synchronize()
+        assert E.GUARD.tripped_sites() > 0
+        if strict:
+            assert E.GUARD.fallbacks > 0
+        else:
+            assert E.GUARD.fallbacks == 0
+            fw = m._run_forward(xd, cd, S, eps=ed, tape=True)          # the host has seen the flags by now
+            out = m._loss_and_backward(fw, xd, 1.0).tolist()
+            assert E.GUARD.fallbacks > 0
+        E.GUARD.check()                                                 # nothing overflowed
+    finally:
+        E.GUARD.strict = was
+        E.GUARD.reset()
+    for v, k in zip(out, ("loss", "elbo", "rll", "kl")):
+        assert abs(v - terms[k]) <= 1e-4 * abs(terms[k]), (strict, k, v, terms[k])
+    gn = float(m._grad_arena.double().pow(2).sum().sqrt())
+    assert abs(gn - norm) <= 2e-3 * norm, (gn, norm)
+
+
+def test_two_piece_guard_raises_on_overflow(dev):
+    """A maximum slot that understates its tensor (here: overwritten after the producer filled it) overflows fp16 in the
+    product that trusts it; the product records non-finite accumulators and ``GUARD.check()`` raises."""
+    from behavio_temporal_vae_amd import engine as E, _native as nv
+    if nv.get_gemm_precision() != "fp32_split2":
+        nv.set_gemm_precision("fp32_split2")
+    E.GUARD.reset()
+    M, K, N = 256, 1000, 128
+    x = torch.randn(M, K, device=dev)
+    W = torch.randn(N, K, device=dev) * 0.1
+    y = torch.empty(M, N, device=dev)
+    part = torch.empty(2, 2, N, device=dev)
+    E.MAX_SLOTS.fresh()
+    xs, ws = E._amax(x), E._amax(W)
+    xs[0] = 1e-3                                  # stale: far below max |x|
+    E._operand_maxima(xs, ws, ("test", "overflow"))
+    nv.call("btvae_linear_relu_stats_fwd", nv.ptr(x), K, nv.ptr(W), nv.ptr(torch.zeros(N, device=dev)), nv.ptr(y), nv.ptr(part), M, K, N)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="non-finite accumulators"):
+        E.GUARD.check()
+    E.GUARD.reset()

@@ -38,7 +38,7 @@ def main():
                 nv.set_gemm_precision(mode)
                 C = torch.empty(M, KO, device=dev)
                 if mode == "fp32_split2":
-                    ma, mw = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+                    ma, mw = torch.zeros(2, device=dev), torch.zeros(2, device=dev)
                     nv.call("btvae_absmax", P(Ad), Ad.numel(), P(ma))
                     nv.call("btvae_absmax", P(Wd), Wd.numel(), P(mw))
                     nv.lib().btvae_gemm_operand_maxima(P(ma), P(mw))

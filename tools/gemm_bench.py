@@ -49,7 +49,7 @@ def main():
 
     def amax(t):
         if id(t) not in mx:
-            mx[id(t)] = torch.zeros(1, device=dev)
+            mx[id(t)] = torch.zeros(2, device=dev)
             nv.call("btvae_absmax", P(t), t.numel(), P(mx[id(t)]))
         return mx[id(t)]
 

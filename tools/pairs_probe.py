@@ -67,8 +67,8 @@ def main():
         nv.call("btvae_pairs_decode", P(Xp), ld, P(sc), P(Xd), ld, M, K)
         err = (Xd[:, :K] - X[:, :K]).abs().max().item()
         print(f"[{data}] round trip max abs err {err:.3e} (max |x| {X.abs().max().item():.3f})")
-        wmax = torch.zeros(1, device=dev)
-        xmax = torch.zeros(1, device=dev)
+        wmax = torch.zeros(2, device=dev)
+        xmax = torch.zeros(2, device=dev)
         nv.call("btvae_absmax", P(W), W.numel(), P(wmax))
         nv.call("btvae_absmax", P(X), X.numel(), P(xmax))
         pl = torch.empty(nv.lib().btvae_weight_planes_elems(N, K), dtype=torch.int16, device=dev)
