@@ -29,8 +29,11 @@ except Exception:  # pragma: no cover
     SummaryWriter = None
 
 
-# Linear products run as fp32 operands split into three bf16 pieces on the bf16 matrix pipe unless a model asks
-# otherwise: measured error against fp64 is at or below the fp32 MFMA kernel's, at 1.35x its speed.
+# Unless a model asks otherwise (``gemm_precision=`` in its config, or BTVAE_GEMM_PRECISION), the Linear products run on two
+# fp16 pieces of each operand value scaled per tensor ("fp32_split2": three matrix instructions per product; error against
+# fp64 at the fp32 MFMA instruction's level while a tensor's values lie within ~2^17 of its maximum).  The engine's guard
+# watches that condition per product and routes a product whose operand breaks it to "fp32_split" (three bf16 pieces: the
+# fp32 values exactly, six matrix instructions), which is also what products without tracked maxima run on.
 DEFAULT_GEMM_PRECISION = os.environ.get("BTVAE_GEMM_PRECISION", "fp32_split2")
 
 

@@ -452,6 +452,30 @@ def wide_benchmark(dev, B, S, steps):
         out[name] = {"value": B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "last_loss": last}
     mac = (552_000 + 5_000_000 + 2 * 24_000) + S * (552_000 + 5_000_000 + 24_000 + 100_000)
     out["train"]["model_tflops"] = mac * 2 * 3 * out["train"]["value"] / 1e12
+    # roofline of the forward products of the train step: the hidden layers (M = S B, N = K = 1000) and, separately, the
+    # decoder's first layer with its K = L + C = 552 reduction -- HIP events around those launches in extra steps
+    from behavio_temporal_vae_amd import _native as nv
+    model.train()
+    hidden_fl, first_fl = 2.0 * S * B * 1000 * 1000, 2.0 * S * B * 1000 * 552
+    roof = {}
+    for tag, lo in (("hidden", 0.9 * hidden_fl), ("hidden_and_first", 0.9 * first_fl)):
+        nv.prof_filter(["gemm_fwd"], lo)
+        nv.prof_enable(True)
+        for i in range(3):
+            train_step(i)
+        torch.cuda.synchronize()
+        roof[tag] = nv.prof_collect()["gemm_fwd"]
+        nv.prof_enable(False)
+    nv.prof_filter(None, 0.0)
+    h_ms, h_fl, _, h_n = roof["hidden"]
+    f_ms, f_fl, f_n = roof["hidden_and_first"][0] - h_ms, roof["hidden_and_first"][1] - h_fl, roof["hidden_and_first"][3] - h_n
+    blocks = {}
+    for tag, ms, fl, cnt, shape in (("hidden_layer", h_ms, h_fl, h_n, f"M={S * B} N=K=1000"), ("first_layer_k552", f_ms, f_fl, f_n, f"M={S * B} N=1000 K=552")):
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        blocks[tag] = {"bound": "mfma", "kernel": f"gemm_bf16_mfma<k-contig,k-contig,relu+stats> {shape}", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS,
+                       "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS, "avg_launch_ms": ms / max(cnt, 1), "launches": cnt,
+                       "traffic": recorded_traffic("wide_" + tag, "bf16", S * B)[0], "traffic_source": recorded_traffic("wide_" + tag, "bf16", S * B)[1]}
+    out["roofline"] = blocks
     return {"metric": "ELBO train samples/sec, wide conditioning (C=528), bf16 GEMM operands", **out,
             "config": {"workload": "config_sweep-style: C=528 (2+2+24+500), D=L=24, H=1000, V=100, on-device Dirichlet conditions",
                        "gemm_precision": "bf16", "per_gpu_batch": B, "num_mc_samples": S}}
@@ -569,9 +593,16 @@ def main():
     nv.prof_collect()
     nv.prof_filter(None, 0.0)
     nv.prof_enable(True)
+    # the other two product families at the same shape (every hidden-layer dX product carries a BatchNorm backward or its
+    # reduction in its epilogue; the weight gradients are split reductions), from the same untimed steps
+    family_dominant = {}
     for i in range(BREAKDOWN_STEPS):
         step(i)
     torch.cuda.synchronize()
+    for fam in ("gemm_dgrad", "gemm_wgrad"):
+        f_ms, f_fl, f_n = nv.prof_dominant(fam)
+        family_dominant[fam] = {"flops_per_launch": f_fl, "avg_launch_ms": f_ms / max(f_n, 1), "launches": f_n,
+                                "achieved_tflops": (f_fl * f_n / (f_ms * 1e-3) / 1e12 if f_ms > 0 else None)}
     prof = nv.prof_collect()
     nv.prof_enable(False)
     loss = last_timed
@@ -667,6 +698,8 @@ def main():
                          "limiter_note": ("fp32_split2: with every MFMA removed this kernel takes 0.397 ms instead of 0.408 at the full clock: "
                                           "its time is set by the global-memory path (activations re-read 8x and the weight image swept from L2, "
                                           "512-byte output row pieces), profiles/r2b_gemm_two_piece_pmc.md") if main_precision == "fp32_split2" else None,
+                         "other_families_dominant": {k: dict(v, frac=(v["achieved_tflops"] / peak if v["achieved_tflops"] else None))
+                                                     for k, v in family_dominant.items()},
                          "fwd_family_tflops": fwd_fl / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else None,
                          "all_gemm_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None,
                          "step_model_tflops": flops_per_sample(S) * B / (ms_step * 1e-3) / 1e12,

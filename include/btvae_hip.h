@@ -31,7 +31,7 @@ int btvae_prof_collect(double* ms, double* flops, double* bytes, long long* laun
 int btvae_prof_dominant(int kind, double* ms, double* flops_per_launch, long long* count);
 
 /* Operand precision of the matrix products.  0 = the fp32 MFMA instruction (the mode the library starts in; the
- * precision torch.nn.Linear runs at in the reference, src/submodels.py:15-17; the Python host mirror selects mode 2
+ * precision torch.nn.Linear runs at in the reference, src/submodels.py:15-17; the Python host mirror selects mode 3 and watches it with the guard below
  * unless a model is configured otherwise).  1 = operands of the Linear-layer products
  * (btvae_linear_*_fwd, _dgrad, _wgrad) rounded to bf16 on the way into LDS, fp32 accumulation; the covariance products
  * stay fp32.  2 = every product fp32-accurate on the bf16 matrix pipe: operands split exactly into three bf16 pieces,

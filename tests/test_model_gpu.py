@@ -339,6 +339,41 @@ def test_wide_conditioning_3d_fp32_and_bf16(dev):
     nv.set_gemm_precision("fp32")
 
 
+@pytest.mark.timeout(600)
+def test_wide_conditioning_at_benchmark_size(dev):
+    """The wide-conditioning leg at the size the benchmark runs it -- C = 528, D = L = 24, H = 1000, B = 4096, S = 16
+    (65,536 decoder rows, first-layer reductions of 552) -- train-mode forward and ELBO terms: bf16 operands within 1e-2
+    of the fp32 oracle, the default fp32-accurate mode within 1e-4."""
+    from oracle import refimpl as R
+    from behavio_temporal_vae_amd.vae_models import CVAE
+    import bench
+    D, C, B, S = 24, 528, 4096, 16
+    torch.manual_seed(12)
+    m = CVAE(input_dim=D, conditioner=Cdim(C), **bench.WIDE_MODEL)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    cfg = {k: bench.WIDE_MODEL[k] for k in ("latent_dim", "distribution_dict")}
+    spec = R.model_spec(D, C, cfg)
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(B, D, generator=gen).add_(1.0).clamp_(-3, 5)
+    topics = torch.distributions.Dirichlet(torch.full((500,), 0.05)).sample((B,))
+    c = torch.cat([torch.randn(B, 28, generator=gen), topics], -1).float()
+    eps = torch.randn(S, B, 24, generator=gen)
+    torch.set_num_threads(min(16, torch.get_num_threads() if torch.get_num_threads() > 1 else 16))
+    lik, post, _ = R.cvae_forward(dict(sd), spec, x, c, eps, True, {})
+    ref = {k: float(v) for k, v in R.elbo_terms(sd, spec, x, lik, post, beta=1.0).items()}
+    m = m.to(dev).train()
+    try:
+        for prec, tol in (("bf16", 1e-2), ("fp32_split2", 1e-4)):
+            m.load_state_dict(sd)
+            m.set_gemm_precision(prec)
+            fw = m._run_forward(x.to(dev), c.to(dev), S, eps=eps.to(dev))
+            got = m._loss_from_forward(fw, x.to(dev), 1.0).tolist()
+            for v, k in zip(got, ("loss", "elbo", "rll", "kl")):
+                assert abs(v - ref[k]) <= tol * abs(ref[k]) + tol * 1e-1, (prec, k, v, ref[k])
+    finally:
+        m.set_gemm_precision("fp32_split2")
+
+
 @pytest.mark.parametrize("bn,dropout,prec", [(True, False, "fp32_split2"), (True, True, "fp32_split"), (False, True, "fp32_split2"), (False, False, "fp32")])
 def test_padded_activation_rows_change_no_bits(dev, monkeypatch, bn, dropout, prec):
     """Hidden activations and gradients in rows padded to a multiple of 32 floats (``engine._rows_on_lines``; width 72 ->
