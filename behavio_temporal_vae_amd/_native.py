@@ -38,6 +38,8 @@ _SIGS = {
     "btvae_absmax": [P, LL, P, P],
     "btvae_slots_zero": [P, I, P],
     "btvae_guard_check": [P, P, I, P],
+    "btvae_weight_image_bf16": [P, I, I, I, I, P, P],
+    "btvae_weight_image_bf16_multi": [P, P, P, P, P, I, P],
     "btvae_linear_head_fwd": [P, I, P, P, I, F, F, P, P, P, I, I, I, P],
     "btvae_linear_head_fwd_ws": [P, I, P, P, I, F, F, P, P, P, P, LL, I, I, I, P],
     "btvae_linear_dgrad": [P, P, P, P, I, I, I, I, P],
@@ -97,6 +99,8 @@ _RET = {
     "btvae_strip_chunks": (c_int, [I]),
     "btvae_bn_relu_bwd_scratch": (c_longlong, [I, I]),
     "btvae_weight_planes_elems": (c_longlong, [I, I]),
+    "btvae_weight_image_bf16_bytes": (c_longlong, [I, I, I]),
+    "btvae_next_bf16": (c_int, [I]),
     "btvae_colsum_noalloc_max_floats": (c_longlong, []),
     "btvae_prof_enabled": (c_int, []),
     "btvae_gemm_operand_maxima": (c_int, [P, P]),
@@ -195,6 +199,7 @@ def call(name: str, *args):
         lib().btvae_gemm_operand_maxima(None, None)
         lib().btvae_output_maximum(None)
         lib().btvae_gemm_guard_site(-1)
+        lib().btvae_next_bf16(0)
         lib().btvae_next_row_pitches(0, 0)
         raise RuntimeError(f"{name}: {msg}")
 

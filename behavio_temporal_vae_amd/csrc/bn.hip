@@ -141,7 +141,9 @@ __global__ void bn_sums_from_products_kernel(const float* __restrict__ col_wp, c
 }
 
 // ---- forward apply: Out = (Y - mean) * invstd * gamma + beta (+ R) ----
-template <int VEC>
+// BF (with VEC == 4): Y, R and Out hold bf16 values (pitch ld in elements); the pad columns between N and ld of Out are
+// written as zeros.
+template <int VEC, bool BF = false>
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ Y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ R,
@@ -161,19 +163,22 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
         } else { sc[j] = 1.f; sh[j] = 0.f; }      // no normalisation: dropout / residual only
     }
     const int r0 = blockIdx.y * rows_per_chunk, r1 = ok ? min(M, r0 + rows_per_chunk) : 0;
+    if (BF && !ok && col < ld) {
+        for (int r = r0 + w; r < min(M, r0 + rows_per_chunk); r += 4) st4x(Out, (size_t)r * ld + col, make_float4(0.f, 0.f, 0.f, 0.f), 1);
+    }
 #pragma unroll 4
     for (int r = r0 + w; r < r1; r += 4) {
         const size_t o = (size_t)r * ld + col, ok_ = (size_t)r * N + col;     // rows ld floats apart; keep flags dense
         if (VEC == 4) {
-            float4 y = *reinterpret_cast<const float4*>(Y + o);
+            float4 y = ld4x(Y, o, BF);
             float4 v = make_float4(y.x * sc[0] + sh[0], y.y * sc[1] + sh[1], y.z * sc[2] + sh[2], y.w * sc[3] + sh[3]);
             if (keep) {
                 const uchar4 k = *reinterpret_cast<const uchar4*>(keep + ok_);
                 v.x = k.x ? v.x * keep_scale : 0.f; v.y = k.y ? v.y * keep_scale : 0.f;
                 v.z = k.z ? v.z * keep_scale : 0.f; v.w = k.w ? v.w * keep_scale : 0.f;
             }
-            if (R) { const float4 q = *reinterpret_cast<const float4*>(R + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-            *reinterpret_cast<float4*>(Out + o) = v;
+            if (R) { const float4 q = ld4x(R, o, BF); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            st4x(Out, o, v, BF);
             vmax = amax4(vmax, v);
         } else {
             float v = Y[o] * sc[0] + sh[0];
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
 }
 
 // ---- backward pass 1: per column s1 = sum g, s2 = sum g * xhat ----
-template <int VEC>
+template <int VEC, bool BF = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ G, const float* __restrict__ Y,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const unsigned char* __restrict__ keep, float keep_scale,
@@ -205,8 +210,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         for (int r = r0 + w; r < r1; r += 4) {
             const size_t o = (size_t)r * ld + col, ok_ = (size_t)r * N + col;     // rows ld floats apart; keep flags dense
             if (VEC == 4) {
-                float4 g = *reinterpret_cast<const float4*>(G + o);
-                const float4 y = *reinterpret_cast<const float4*>(Y + o);
+                float4 g = ld4x(G, o, BF);
+                const float4 y = ld4x(Y, o, BF);
                 if (keep) {
                     const uchar4 k = *reinterpret_cast<const uchar4*>(keep + ok_);
                     g.x = k.x ? g.x * keep_scale : 0.f; g.y = k.y ? g.y * keep_scale : 0.f;
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 }
 
 // ---- backward pass 2: dPre = (y>0) * gamma*invstd * (g - dbeta/M - xhat*dgamma/M); column sums of dPre ----
-template <int VEC>
+template <int VEC, bool BF = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ Y,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ dgamma,
@@ -314,13 +319,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         sb[j] = 0.f;
     }
     const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    if (BF && !ok && col < ld) {
+        for (int r = r0 + w; r < r1; r += 4) st4x(dPre, (size_t)r * ld + col, make_float4(0.f, 0.f, 0.f, 0.f), 1);
+    }
     if (ok) {
 #pragma unroll 4
         for (int r = r0 + w; r < r1; r += 4) {
             const size_t o = (size_t)r * ld + col, ok_ = (size_t)r * N + col;     // rows ld floats apart; keep flags dense
             if (VEC == 4) {
-                float4 g = *reinterpret_cast<const float4*>(G + o);
-                const float4 y = *reinterpret_cast<const float4*>(Y + o);
+                float4 g = ld4x(G, o, BF);
+                const float4 y = ld4x(Y, o, BF);
                 if (keep) {
                     const uchar4 k = *reinterpret_cast<const uchar4*>(keep + ok_);
                     g.x = k.x ? g.x * keep_scale : 0.f; g.y = k.y ? g.y * keep_scale : 0.f;
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 d.y = y.y > 0.f ? k0[1] * g.y - k1[1] - k2[1] * ((y.y - mu[1]) * is[1]) : 0.f;
                 d.z = y.z > 0.f ? k0[2] * g.z - k1[2] - k2[2] * ((y.z - mu[2]) * is[2]) : 0.f;
                 d.w = y.w > 0.f ? k0[3] * g.w - k1[3] - k2[3] * ((y.w - mu[3]) * is[3]) : 0.f;
-                *reinterpret_cast<float4*>(dPre + o) = d;
+                st4x(dPre, o, d, BF);
                 vmax = amax4(vmax, d);
                 sb[0] += d.x; sb[1] += d.y; sb[2] += d.z; sb[3] += d.w;
             } else {
@@ -408,6 +416,13 @@ inline bool vec4_ok(int N, int ld, const void* a, const void* b, const void* c, 
 #define BTVAE_TAKE_LD(what) \
     const int ld = [&] { const RowPitches rp = take_row_pitches(); return rp.n ? rp.n : N; }(); \
     BTVAE_REQUIRE(ld >= N, what ": row pitch %d below N = %d", ld, N)
+
+// this call's [M, N] matrices hold bf16 values (btvae_next_bf16): 8-byte accesses of four elements, pitch a multiple of 4
+#define BTVAE_TAKE_BF16(what) \
+    const bool bf = take_bf16_mask() != 0; \
+    BTVAE_REQUIRE(!bf || (N % 4 == 0 && ld % 4 == 0), what ": bf16-stored matrices need N and the pitch to be multiples of 4 (N %d, pitch %d)", N, ld)
+
+inline bool al8(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 
 inline int chunk_count(int M) { return std::max(1, std::min(256, (M + 63) / 64)); }
 
@@ -500,12 +515,16 @@ BTVAE_API int btvae_bn_apply_fwd(const float* Y, const float* mean, const float*
                                  const float* R, const unsigned char* keep, float keep_scale, float* Out, int M, int N,
                                  void* stream) {
     BTVAE_TAKE_LD("bn_apply_fwd");
+    BTVAE_TAKE_BF16("bn_apply_fwd");
     float* amax_out = take_output_maximum();
     BTVAE_REQUIRE(Y && Out, "bn_apply_fwd: null pointer");
     BTVAE_REQUIRE(mean ? (invstd && gamma && beta) : (!invstd && !gamma && !beta), "bn_apply_fwd: pass all four BatchNorm vectors or none");
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
     ProfScope ps(PK_BN, (hipStream_t)stream, 0, 4.0 * M * N * (R ? 3 : 2) + (keep ? 1.0 * M * N : 0.0));
-    if (vec4_ok(N, ld, Y, R, Out, keep))
+    if (bf) {
+        BTVAE_REQUIRE(al8(Y) && al8(R) && al8(Out) && (!keep || (reinterpret_cast<uintptr_t>(keep) & 3) == 0), "bn_apply_fwd: bf16-stored matrices must be 8-byte aligned");
+        hipLaunchKernelGGL((bn_apply_fwd_kernel<4, true>), dim3((ld + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, keep, keep_scale, Out, M, N, ld, rpc, amax_out);
+    } else if (vec4_ok(N, ld, Y, R, Out, keep))
         hipLaunchKernelGGL((bn_apply_fwd_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, keep, keep_scale, Out, M, N, ld, rpc, amax_out);
     else
         hipLaunchKernelGGL((bn_apply_fwd_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, keep, keep_scale, Out, M, N, ld, rpc, amax_out);
@@ -521,6 +540,7 @@ BTVAE_API int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mea
                                 float* dgamma, float* dbeta, float* dbias, float* dbias_cur, float* dPre, float* scratch, int M, int N,
                                 int accumulate, void* stream) {
     BTVAE_TAKE_LD("bn_relu_bwd");
+    BTVAE_TAKE_BF16("bn_relu_bwd");
     float* amax_out = take_output_maximum();
     BTVAE_REQUIRE(G && Y && mean && invstd && gamma && dgamma && dbeta && dbias && dPre && scratch, "bn_relu_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -529,13 +549,15 @@ BTVAE_API int btvae_bn_relu_bwd(const float* G, const float* Y, const float* mea
     float* p1 = scratch + (size_t)2 * chunks * N;   // [chunks][N]
     const bool v4 = vec4_ok(N, ld, G, Y, dPre, keep);
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 5 + (keep ? 2.0 * M * N : 0.0));
-    if (v4) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, p2, M, N, ld, rpc);
+    if (bf) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, p2, M, N, ld, rpc);
+    else if (v4) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, p2, M, N, ld, rpc);
     else    hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, p2, M, N, ld, rpc);
     // k=0 -> sum g (dbeta), k=1 -> sum g*xhat (dgamma); current-batch values go to the tail of the scratch
     float* cur_dbeta = scratch + (size_t)3 * chunks * N;
     float* cur_dgamma = cur_dbeta + N;
     colsum_finalize(s, p2, chunks, 2, N, dbeta, dgamma, cur_dbeta, cur_dgamma, accumulate);
-    if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, ld, rpc, 1.f / (float)M, amax_out);
+    if (bf) hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), dim3((ld + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, ld, rpc, 1.f / (float)M, amax_out);
+    else if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, ld, rpc, 1.f / (float)M, amax_out);
     else    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, cur_dgamma, cur_dbeta, keep, keep_scale, dPre, p1, M, N, ld, rpc, 1.f / (float)M, amax_out);
     colsum_finalize(s, p1, chunks, 1, N, dbias, (float*)nullptr, dbias_cur, (float*)nullptr, accumulate);
     return check_launch("bn_relu_bwd");
@@ -559,11 +581,13 @@ BTVAE_API int btvae_bn_relu_bwd_sums(const float* G, const float* Y, const float
                                      const unsigned char* keep, float keep_scale, float* dgamma, float* dbeta, float* sums,
                                      float* scratch, int M, int N, int accumulate, void* stream) {
     BTVAE_TAKE_LD("bn_relu_bwd_sums");
+    BTVAE_TAKE_BF16("bn_relu_bwd_sums");
     BTVAE_REQUIRE(G && Y && mean && invstd && dgamma && dbeta && sums && scratch, "bn_relu_bwd_sums: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 2 + (keep ? 1.0 * M * N : 0.0));
-    if (vec4_ok(N, ld, G, Y, nullptr, keep)) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, scratch, M, N, ld, rpc);
+    if (bf) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, scratch, M, N, ld, rpc);
+    else if (vec4_ok(N, ld, G, Y, nullptr, keep)) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, scratch, M, N, ld, rpc);
     else                                 hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, keep, keep_scale, scratch, M, N, ld, rpc);
     colsum_finalize(s, scratch, chunks, 2, N, dbeta, dgamma, sums, sums + N, accumulate);
     return check_launch("bn_relu_bwd_sums");
@@ -585,6 +609,7 @@ BTVAE_API int btvae_bn_relu_bwd_apply(const float* G, const float* Y, const floa
                                       const unsigned char* keep, float keep_scale, const float* sums, long long total_rows,
                                       float* dbias, float* dbias_cur, float* dPre, float* scratch, int M, int N, int accumulate, void* stream) {
     BTVAE_TAKE_LD("bn_relu_bwd_apply");
+    BTVAE_TAKE_BF16("bn_relu_bwd_apply");
     float* amax_out = take_output_maximum();
     BTVAE_REQUIRE(G && Y && mean && invstd && gamma && sums && dbias && dPre && scratch, "bn_relu_bwd_apply: null pointer");
     BTVAE_REQUIRE(total_rows >= M, "bn_relu_bwd_apply: total_rows %lld < local rows %d", total_rows, M);
@@ -592,7 +617,9 @@ BTVAE_API int btvae_bn_relu_bwd_apply(const float* G, const float* Y, const floa
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
     const float inv = 1.f / (float)total_rows;
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 3 + (keep ? 1.0 * M * N : 0.0));
-    if (vec4_ok(N, ld, G, Y, dPre, keep))
+    if (bf)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), dim3((ld + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, ld, rpc, inv, amax_out);
+    else if (vec4_ok(N, ld, G, Y, dPre, keep))
         hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, ld, rpc, inv, amax_out);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, mean, invstd, gamma, sums + N, sums, keep, keep_scale, dPre, scratch, M, N, ld, rpc, inv, amax_out);
@@ -605,13 +632,16 @@ BTVAE_API int btvae_bn_relu_bwd_apply(const float* G, const float* Y, const floa
 BTVAE_API int btvae_relu_bwd(const float* G, const float* Y, const unsigned char* keep, float keep_scale, float* dbias,
                              float* dbias_cur, float* dPre, float* scratch, int M, int N, int accumulate, void* stream) {
     BTVAE_TAKE_LD("relu_bwd");
+    BTVAE_TAKE_BF16("relu_bwd");
     float* amax_out = take_output_maximum();
     BTVAE_REQUIRE(G && Y && dbias && dPre && scratch, "relu_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = chunk_count(M), rpc = (M + chunks - 1) / chunks;
     const float* none = nullptr;
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N * 3 + (keep ? 1.0 * M * N : 0.0));
-    if (vec4_ok(N, ld, G, Y, dPre, keep))
+    if (bf)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), dim3((ld + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, ld, rpc, 1.f, amax_out);
+    else if (vec4_ok(N, ld, G, Y, dPre, keep))
         hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3((N + STRIP_COLS - 1) / STRIP_COLS, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, ld, rpc, 1.f, amax_out);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, s, G, Y, none, none, none, none, none, keep, keep_scale, dPre, scratch, M, N, ld, rpc, 1.f, amax_out);

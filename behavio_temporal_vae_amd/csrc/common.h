@@ -47,6 +47,13 @@ constexpr int GUARD_SITES = 2048;
 int guard_range_log2();          // the range (log2) beyond which a region counts as far below its tensor's maximum
 int* take_guard_site();
 
+// Hidden activations and gradients stored as bf16 (the bf16 mode's storage format): which matrices of the next launch
+// from this thread hold bf16 values -- the A operand, the output, the add-in together with the BatchNorm input, the B
+// operand of a weight gradient (btvae_next_bf16); the call returns the mask and clears the request.  Pitches of such
+// matrices count bf16 elements.
+enum : int { BF16_A = 1, BF16_OUT = 2, BF16_AUX = 4, BF16_B = 8 };
+int take_bf16_mask();
+
 // Row pitches (in floats; 0 = dense) that the next launch from this thread applies to its activation / gradient matrices
 // with N and with K columns (btvae_next_row_pitches); the call returns them and clears the request.
 struct RowPitches { int n, k; };
@@ -129,6 +136,21 @@ __device__ __forceinline__ void block_amax_commit(float m, float* out) {
 __device__ __forceinline__ float amax4(float m, const float4 v) {
     return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
+// four consecutive elements at element index `i` of a matrix that holds fp32 or (bf != 0) bf16 values
+__device__ __forceinline__ float4 ld4x(const float* base, size_t i, int bf) {
+    if (!bf) return *reinterpret_cast<const float4*>(base + i);
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + i);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ void st4x(float* base, size_t i, const float4 v, int bf) {
+    if (!bf) { *reinterpret_cast<float4*>(base + i) = v; return; }
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 lo = {v.x, v.y}, hi = {v.z, v.w};
+    const unsigned a = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, b2)), b = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, b2));
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + i) = make_uint2(a, b);
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

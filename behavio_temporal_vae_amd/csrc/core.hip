@@ -64,6 +64,9 @@ void prof_end(int kind, hipStream_t s) {
 static thread_local float* t_out_max = nullptr;
 float* take_output_maximum() { float* p = t_out_max; t_out_max = nullptr; return p; }
 
+static thread_local int t_bf16_mask = 0;
+int take_bf16_mask() { const int m = t_bf16_mask; t_bf16_mask = 0; return m; }
+
 static thread_local RowPitches t_pitches = {0, 0};
 RowPitches take_row_pitches() { const RowPitches p = t_pitches; t_pitches = RowPitches{0, 0}; return p; }
 
@@ -163,6 +166,19 @@ BTVAE_API int btvae_output_maximum(float* amax_out) { t_out_max = amax_out; retu
 BTVAE_API int btvae_next_row_pitches(int ld_n, int ld_k) {
     BTVAE_REQUIRE(ld_n >= 0 && ld_k >= 0, "next_row_pitches: negative pitch");
     t_pitches = RowPitches{ld_n, ld_k};
+    return 0;
+}
+
+// bf16 storage of hidden activations and gradients (what the Python engine uses in the bf16 mode): the next launch, from
+// the calling thread, of a Linear product or a BatchNorm / ReLU kernel treats the named matrices as bf16 (2 bytes per
+// element, pitches in elements): bit 0 the A operand (X of a forward product, dY of a dX or weight-gradient product),
+// bit 1 the output (Y / Out / dX / dPre), bit 2 the add-in R and the BatchNorm input Yb, bit 3 the B operand of a weight
+// gradient (X).  For btvae_bn_apply_fwd, btvae_bn_relu_bwd*, btvae_relu_bwd any non-zero mask means all their [M, N]
+// matrices.  Producers write zeros into the pad columns between N and the pitch: the 256-wide forward / dX kernels
+// copy whole 64-byte row pieces.  Consumed by that launch.
+BTVAE_API int btvae_next_bf16(int mask) {
+    BTVAE_REQUIRE(mask >= 0 && mask < 16, "next_bf16: mask %d out of range", mask);
+    t_bf16_mask = mask;
     return 0;
 }
 

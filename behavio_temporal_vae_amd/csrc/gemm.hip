@@ -15,9 +15,7 @@
 #include "gemm_bf16.h"
 #include "gemm_split.h"
 #include "gemm_head64.h"
-#ifdef BTVAE_EXPERIMENTS
-#include "gemm_pq256.h"      // pair-format operands (pairs.h): measured and not adopted, see tools/pairs_probe.py
-#endif
+#include "gemm_pq256.h"      // 256-wide DMA-fed kernel: its bf16 form serves the bf16 mode; the pair-format form is an experiment (tools/pairs_probe.py)
 #include <algorithm>
 #include <cstdlib>
 #include <atomic>
@@ -481,6 +479,78 @@ __global__ __launch_bounds__(64) void slots_zero_kernel(const SlotRuns r) {
 struct AbsmaxBatch { const float* x[16]; float* out[16]; size_t n[16]; };
 __global__ __launch_bounds__(256) void absmax_multi_kernel(const AbsmaxBatch b) { absmax_body(b.x[blockIdx.y], b.n[blockIdx.y], b.out[blockIdx.y]); }
 
+// bf16 matrix B[n][k] as the stage images of the bf16 form of gemm_pq256: blocks [ceil(Nn/256)][ceil(Kk/32)] of 256 rows x
+// 64 bytes, piece c of a row = k 8c .. 8c+7, zero padded.  One thread per row and piece.
+__global__ __launch_bounds__(256) void weight_image_bf16_kernel(const float* __restrict__ W, int ldw, int Nn, int Kk, int transpose,
+                                                                char* __restrict__ image) {
+    const int KT = (Kk + 31) >> 5;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)((Nn + 255) >> 8) * KT * 1024) return;
+    const int c = (int)(idx & 3), nl = (int)((idx >> 2) & 255);
+    const size_t blk = idx >> 10;
+    const int kt = (int)(blk % KT), n = (int)(blk / KT) * 256 + nl, k0 = kt * 32 + c * 8;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        v[i] = (n < Nn && k0 + i < Kk) ? (transpose ? W[(size_t)(k0 + i) * ldw + n] : W[(size_t)n * ldw + k0 + i]) : 0.f;
+    *reinterpret_cast<uint4*>(image + blk * QST_B + q_off(nl, c)) =
+        make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// several matrices in one launch: blockIdx.y selects the entry (an entry is one image of one matrix)
+constexpr int IMAGES_BATCH = 32;
+struct ImagesBatch { const float* W[IMAGES_BATCH]; char* image[IMAGES_BATCH]; int ldw[IMAGES_BATCH], Nn[IMAGES_BATCH], Kk[IMAGES_BATCH], transpose[IMAGES_BATCH]; };
+
+inline long long bf16_image_bytes(int R, int C, bool transpose) {
+    const int Nn = transpose ? C : R, Kk = transpose ? R : C;
+    return (long long)((Nn + 255) / 256) * ((Kk + 31) / 32) * QST_B;
+}
+
+__global__ __launch_bounds__(256) void weight_image_bf16_multi_kernel(const ImagesBatch b) {
+    const int e = blockIdx.y;
+    const int KT = (b.Kk[e] + 31) >> 5, Nn = b.Nn[e], Kk = b.Kk[e], ldw = b.ldw[e], transpose = b.transpose[e];
+    const float* __restrict__ W = b.W[e];
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)((Nn + 255) >> 8) * KT * 1024) return;
+    const int c = (int)(idx & 3), nl = (int)((idx >> 2) & 255);
+    const size_t blk = idx >> 10;
+    const int kt = (int)(blk % KT), n = (int)(blk / KT) * 256 + nl, k0 = kt * 32 + c * 8;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        v[i] = (n < Nn && k0 + i < Kk) ? (transpose ? W[(size_t)(k0 + i) * ldw + n] : W[(size_t)n * ldw + k0 + i]) : 0.f;
+    *reinterpret_cast<uint4*>(b.image[e] + blk * QST_B + q_off(nl, c)) =
+        make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+}
+
+// Launch of the bf16 form of gemm_pq256: A = bf16 activations / gradients (pitch a.lda elements, a multiple of 32 that
+// covers K rounded up to 32, pad columns finite), B = a.Bp, the stage images of the weight for this direction.
+template <int EPI>
+int launch_bh256(GemmArgs& a, int groups, hipStream_t s, const char* what) {
+    a.amax_a = a.amax_b = nullptr; a.guard = nullptr;
+    a.amax_out = nullptr;
+    BTVAE_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "%s: empty problem M=%d N=%d K=%d", what, a.M, a.N, a.K);
+    BTVAE_REQUIRE(a.A && a.Bp && a.C, "%s: null operand", what);
+    BTVAE_REQUIRE(a.lda % 32 == 0 && a.lda >= (a.K + 31) / 32 * 32 && aligned16(a.A), "%s: a bf16 activation operand needs a 16-byte aligned base and a pitch that is a multiple of 32 covering K rounded up to 32 (K %d, pitch %d)", what, a.K, a.lda);
+    BTVAE_REQUIRE(a.ldc >= a.N && a.ldc % 4 == 0 && a.N % 4 == 0 && aligned16(a.C), "%s: output needs N %% 4 == 0 and a pitch that is a multiple of 4 (N %d, pitch %d)", what, a.N, a.ldc);
+    BTVAE_REQUIRE(a.c_vec, "%s: add-in / second outputs not 16-byte addressable", what);
+    a.tiles_m = (a.M + 128 * groups - 1) / (128 * groups);
+    a.tiles_n = (a.N + QN - 1) / QN;
+    a.bp_tiles = (a.K + 31) / 32;
+    a.a_vec = a.b_vec = 1;
+    a.kchunk = a.bp_tiles * 32;
+    if (groups == 2) hipLaunchKernelGGL((gemm_pq256<EPI, 2, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), 0, s, a);
+    else             hipLaunchKernelGGL((gemm_pq256<EPI, 1, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, s, a);
+    return btvae::check_launch(what);
+}
+
+// epilogues the 256-wide bf16 kernel is built with (the hidden-layer products of the bf16 mode)
+template <int EPI> constexpr bool has_bh256() {
+    return EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE || EPI == EPI_PLAIN || EPI == EPI_GSTATS || EPI == EPI_BNBWD || EPI == EPI_HEAD;
+}
+
 // which kernels exist with two fp16 pieces per operand value: the Linear layers' products
 template <int AL, int BL, int EPI> constexpr bool has_twopiece() {
     return (AL == LAY_K && BL == LAY_K && (EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE || EPI == EPI_HEAD)) ||
@@ -501,7 +571,6 @@ template <int AL, int BL, int EPI> constexpr bool has_presplit() {
                            (BL == LAY_M && (EPI == EPI_PLAIN || EPI == EPI_BNBWD || EPI == EPI_GSTATS)));
 }
 
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // 0: fp32 MFMA, 1: bf16 operands, 2: fp32 operands as three bf16 pieces, 3: as 2 but two scaled fp16 pieces in the
 // products that were given their operands' absolute maxima
@@ -531,10 +600,34 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
               (EPI != EPI_MUL || (a.lde % 4 == 0 && aligned16(a.E1) && aligned16(a.E2)));
     if (splits < 1) splits = 1;
     const int prec = g_precision.load(std::memory_order_relaxed);
+    // matrices stored as bf16 (btvae_next_bf16): bf16 mode only, staged epilogue only, extents in whole 16-byte pieces
+    const int bmask = btvae::take_bf16_mask();
+    a.a_bf16 = (bmask & btvae::BF16_A) != 0; a.c_bf16 = (bmask & btvae::BF16_OUT) != 0;
+    a.r_bf16 = (bmask & btvae::BF16_AUX) != 0; a.b_bf16 = (bmask & btvae::BF16_B) != 0;
+    if (bmask) {
+        BTVAE_REQUIRE(reduced_ok && prec == 1, "%s: bf16-stored matrices are a feature of the bf16 mode's Linear products", what);
+        BTVAE_REQUIRE(a.c_vec, "%s: bf16-stored matrices need 16-byte addressable outputs and add-ins (N %% 4 == 0, pitches %% 4 == 0)", what);
+        if (a.a_bf16) a.a_vec = (a.lda % 8 == 0) && aligned16(a.A) && ((AL == LAY_K ? a.K : a.M) % 8 == 0);
+        if (a.b_bf16) a.b_vec = (a.ldb % 8 == 0) && aligned16(a.B) && ((BL == LAY_K ? a.K : a.N) % 8 == 0);
+        BTVAE_REQUIRE(a.a_vec && a.b_vec, "%s: a bf16-stored operand needs a 16-byte aligned base, a pitch and an extent that are multiples of 8", what);
+        BTVAE_REQUIRE(!a.b_bf16 || (AL == LAY_M && BL == LAY_M), "%s: only a weight gradient takes a bf16-stored B operand", what);
+        BTVAE_REQUIRE(!a.a_bf16 || AL == LAY_K || (AL == LAY_M && BL == LAY_M), "%s: no kernel for this bf16-stored A operand", what);
+    }
     const bool bf16 = reduced_ok && prec == 1 && a.a_vec && a.b_vec;
-    const bool split = prec >= 2 && a.a_vec && a.b_vec;          // fp32-accurate: every product may use it
+    if constexpr (AL == LAY_K && has_bh256<EPI>()) {
+        // hidden-layer product on a bf16-stored activation with the weight's stage images: the 256-wide DMA-fed kernel
+        // (128-row workgroups while 256-row ones would not fill the chip)
+        if (bf16 && a.a_bf16 && a.Bp && splits == 1 && a.lda % 32 == 0 && a.lda >= (a.K + 31) / 32 * 32) {
+            const int wide_tiles = ((a.M + 255) / 256) * ((a.N + QN - 1) / QN);
+            const bool long_epilogue = EPI == EPI_GSTATS || EPI == EPI_BNBWD;      // runs beside a second workgroup's main loop
+            return launch_bh256<EPI>(a, (wide_tiles >= 256 && !long_epilogue) ? 2 : 1, s, what);
+        }
+    }
+    // fp32-accurate on the bf16 pipe: every product of the split modes, and in the bf16 mode the products that must not
+    // round their operands (the likelihood's covariance products)
+    const bool split = (prec >= 2 || (prec == 1 && !reduced_ok)) && a.a_vec && a.b_vec;
     const bool two = split && prec == 3 && has_twopiece<AL, BL, EPI>() && a.amax_a && a.amax_b;
-    if (prec == 3 && !two) a.Bp = nullptr;                       // planes made in this mode hold fp16 pieces
+    if ((prec == 3 && !two) || prec == 1) a.Bp = nullptr;        // planes made in these modes hold fp16 pieces / bf16 stage images
     // 128 x 256 block tile: the weight gradients, whose two operands are both split in the kernel (+5-10 %; the products
     // with a pre-split weight gain nothing from it and short reductions lose to its longer epilogue)
     const bool wide = two && AL == LAY_M && a.N > BN && a.K >= 256;
@@ -543,7 +636,18 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     a.kchunk = (((a.K + splits - 1) / splits) + bk - 1) / bk * bk;
     splits = (a.K + a.kchunk - 1) / a.kchunk;
     dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, (unsigned)splits);
-    if (bf16)                    hipLaunchKernelGGL((gemm_bf16_mfma<AL, BL, EPI>), grid, dim3(256), 0, s, a);
+    if (bf16) {
+        bool done = false;
+        if constexpr (AL == LAY_K && EPI != EPI_MUL) {
+            if (a.a_bf16) { done = true; hipLaunchKernelGGL((gemm_bf16_mfma<AL, BL, EPI, true, false>), grid, dim3(256), 0, s, a); }
+        }
+        if constexpr (AL == LAY_M && BL == LAY_M && EPI == EPI_PLAIN) {
+            if (a.a_bf16 && a.b_bf16)  { done = true; hipLaunchKernelGGL((gemm_bf16_mfma<AL, BL, EPI, true, true>), grid, dim3(256), 0, s, a); }
+            else if (a.a_bf16)         { done = true; hipLaunchKernelGGL((gemm_bf16_mfma<AL, BL, EPI, true, false>), grid, dim3(256), 0, s, a); }
+            else if (a.b_bf16)         { done = true; hipLaunchKernelGGL((gemm_bf16_mfma<AL, BL, EPI, false, true>), grid, dim3(256), 0, s, a); }
+        }
+        if (!done) hipLaunchKernelGGL((gemm_bf16_mfma<AL, BL, EPI>), grid, dim3(256), 0, s, a);
+    }
     else if (split) {
         bool pre = false;
         if constexpr (has_presplit<AL, BL, EPI>()) {
@@ -844,6 +948,10 @@ namespace {
 // (W rows = reduction index) product
 inline void set_planes(GemmArgs& a, const void* planes, int N, int K, bool dx) {
     if (!planes || !aligned16(planes)) return;
+    if (g_precision.load(std::memory_order_relaxed) == 1) {      // bf16 mode: stage images (btvae_weight_image_bf16)
+        a.Bp = reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(planes) + (dx ? bf16_image_bytes(N, K, false) : 0));
+        return;
+    }
     a.Bp = (const unsigned short*)planes + (dx ? planes_f_elems(N, K) : 0);
     a.bp_tiles = dx ? (N + 15) / 16 : (K + 15) / 16;
 }
@@ -866,6 +974,53 @@ BTVAE_API int btvae_linear_relu_stats_fwd_pw(const float* X, int ldx, const floa
 BTVAE_API int btvae_linear_relu_stats_fwd(const float* X, int ldx, const float* W, const float* b, float* Y,
                                           float* stat_partials, int M, int K, int N, void* stream) {
     return btvae_linear_relu_stats_fwd_pw(X, ldx, W, nullptr, b, Y, stat_partials, M, K, N, stream);
+}
+
+// bf16 mode, hidden layers: stage images of a weight matrix W[R][C] for the 256-wide products whose activation operand is
+// stored as bf16 (btvae_next_bf16): one image per direction in `image` -- the forward image (output columns = rows of W)
+// at its start, the dX image (output columns = columns of W) btvae_weight_image_bf16_bytes(R, C, 0) bytes further.
+// `which`: 1 forward, 2 dX, 3 both.  The *_pw entry points take `image` as their Wplanes argument in that mode.
+BTVAE_API long long btvae_weight_image_bf16_bytes(int R, int C, int transpose) {
+    if (R <= 0 || C <= 0) return 0;
+    return bf16_image_bytes(R, C, transpose != 0);
+}
+BTVAE_API int btvae_weight_image_bf16(const float* W, int ldw, int R, int C, int which, void* image, void* stream) {
+    BTVAE_REQUIRE(W && image && R > 0 && C > 0 && ldw >= C && aligned16(image), "weight_image_bf16: bad arguments");
+    BTVAE_REQUIRE(which >= 1 && which <= 3, "weight_image_bf16: which = %d (1: forward image, 2: dX image, 3: both)", which);
+    for (int t = 0; t < 2; ++t) {
+        if (!((which >> t) & 1)) continue;
+        const int Nn = t ? C : R, Kk = t ? R : C;
+        const size_t threads = (size_t)((Nn + 255) / 256) * ((Kk + 31) / 32) * 1024;
+        hipLaunchKernelGGL(weight_image_bf16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           W, ldw, Nn, Kk, t, (char*)image + (t ? bf16_image_bytes(R, C, false) : 0));
+    }
+    return check_launch("weight_image_bf16");
+}
+// The same for `count` contiguous matrices W[i][N[i]][K[i]] (host arrays of length count), one launch per 32 images.
+BTVAE_API int btvae_weight_image_bf16_multi(const float* const* W, const int* N, const int* K, void* const* image, const int* which,
+                                            int count, void* stream) {
+    BTVAE_REQUIRE(W && N && K && image && which && count > 0, "weight_image_bf16_multi: bad arguments");
+    ImagesBatch b{};
+    int n = 0;
+    size_t most = 0;
+    auto flush = [&]() {
+        if (n) hipLaunchKernelGGL(weight_image_bf16_multi_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, b);
+        n = 0; most = 0;
+    };
+    for (int j = 0; j < count; ++j) {
+        BTVAE_REQUIRE(W[j] && image[j] && aligned16(image[j]) && N[j] > 0 && K[j] > 0 && which[j] >= 1 && which[j] <= 3, "weight_image_bf16_multi: entry %d: bad arguments", j);
+        for (int t = 0; t < 2; ++t) {
+            if (!((which[j] >> t) & 1)) continue;
+            if (n == IMAGES_BATCH) flush();
+            b.W[n] = W[j]; b.ldw[n] = K[j]; b.transpose[n] = t;
+            b.Nn[n] = t ? K[j] : N[j]; b.Kk[n] = t ? N[j] : K[j];
+            b.image[n] = (char*)image[j] + (t ? bf16_image_bytes(N[j], K[j], false) : 0);
+            most = std::max(most, (size_t)((b.Nn[n] + 255) / 256) * ((b.Kk[n] + 31) / 32) * 1024);
+            ++n;
+        }
+    }
+    flush();
+    return check_launch("weight_image_bf16_multi");
 }
 
 #ifdef BTVAE_EXPERIMENTS
@@ -919,6 +1074,17 @@ BTVAE_API int btvae_weight_image_pq(const float* W, int ldw, int R, int C, int t
                        W, ldw, Nn, Kk, transpose, (char*)image, amax);
     return check_launch("weight_image_pq");
 }
+// Y (bf16, pitch ldy elements) = relu(X (bf16, pitch ldx elements) W^T + b), W from its bf16 stage images
+BTVAE_API int btvae_linear_relu_stats_fwd_bh256(const void* X, int ldx, const void* Wimage, const float* b, void* Y, int ldy,
+                                                float* stat_partials, int M, int K, int N, int groups, void* stream) {
+    BTVAE_REQUIRE(groups == 1 || groups == 2, "linear_relu_stats_fwd_bh256: groups %d", groups);
+    BTVAE_REQUIRE(b && stat_partials, "linear_relu_stats_fwd_bh256: null bias/stats");
+    GemmArgs a{}; a.A = (const float*)X; a.lda = ldx; a.C = (float*)Y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
+    a.bias = b; a.stats = stat_partials; a.Bp = (const unsigned short*)Wimage; a.c_bf16 = 1;
+    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N));
+    return launch_bh256<EPI_RELU_STATS>(a, groups, (hipStream_t)stream, "linear_relu_stats_fwd_bh256");
+}
+
 BTVAE_API int btvae_linear_relu_stats_fwd_pq256(const void* Xp, int ldx, const float* xsc, const void* Wimage, const float* wmax, const float* b,
                                                 float* Y, float* stat_partials, int M, int K, int N, int groups, void* stream) {
     const RowPitches rp = take_row_pitches();

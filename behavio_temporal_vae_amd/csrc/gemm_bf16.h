@@ -86,6 +86,43 @@ __device__ __forceinline__ void h_r2s(__bf16* S, int tid, const Stage& st) {
     }
 }
 
+// An operand that is already bf16 in HBM (hidden activations / gradients in the bf16 storage mode): its 128 x 32 tile is
+// 8 KiB = two 16-byte pieces per thread, stored to LDS as they are.  LAY_K: piece f covers row f >> 2, k = 8 (f & 3) .. + 7.
+// LAY_M: k row f >> 4, m = 8 (f & 15) .. + 7.
+struct HStage { uint4 v[2]; };
+
+template <int LAY, bool FULL>
+__device__ __forceinline__ void hb_g2r(const float* __restrict__ Pf, int ld, int row0, int nrows, int k0, int kend, int tid, HStage& st) {
+    const unsigned short* P = reinterpret_cast<const unsigned short*>(Pf);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int f = tid + 256 * q;
+        uint4 a = make_uint4(0u, 0u, 0u, 0u);
+        if (LAY == LAY_K) {
+            const int gr = row0 + (f >> 2), gk = k0 + ((f & 3) << 3);
+            const unsigned short* src = P + (size_t)min(gr, nrows - 1) * ld + gk;
+            if (FULL) a = *reinterpret_cast<const uint4*>(src);
+            else if (gr < nrows && gk + 7 < kend) a = *reinterpret_cast<const uint4*>(src);
+        } else {
+            const int gk = k0 + (f >> 4), gm = row0 + ((f & 15) << 3);
+            if (FULL) a = *reinterpret_cast<const uint4*>(P + (size_t)gk * ld + min(gm, nrows - 8));
+            else if (gk < kend && gm + 7 < nrows) a = *reinterpret_cast<const uint4*>(P + (size_t)gk * ld + gm);
+        }
+        st.v[q] = a;
+    }
+}
+template <int LAY>
+__device__ __forceinline__ void hb_r2s(__bf16* S, int tid, const HStage& st) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int f = tid + 256 * q;
+        __bf16* dst = LAY == LAY_K ? S + (f >> 2) * HLD + ((f & 3) << 3) : S + (f >> 4) * HMP + ((f & 15) << 3);
+        *reinterpret_cast<uint4*>(dst) = st.v[q];
+    }
+}
+template <bool H> struct HStageOf { typedef Stage type; };
+template <> struct HStageOf<true> { typedef HStage type; };
+
 // MFMA operand of k step s (16 k) for the 32-row block at `blk`: row = lane & 31, k = 16s + 8*(lane>>5) .. +7.
 // Every lane must be active at the transposing reads.
 template <int LAY>
@@ -98,7 +135,8 @@ __device__ __forceinline__ bf16x8 h_frag(const __bf16* S, int blk, int s, int la
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int AL, int BL, int EPI>
+// A16 / B16: that operand is bf16 in HBM already (pitch in bf16 elements, extents multiples of 8).
+template <int AL, int BL, int EPI, bool A16 = false, bool B16 = false>
 __global__ __launch_bounds__(256, 3) void gemm_bf16_mfma(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[2][2][HTILE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -120,12 +158,24 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_mfma(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    Stage sa, sb;
+    typename HStageOf<A16>::type sa;
+    typename HStageOf<B16>::type sb;
+    auto load_a = [&](int k0, auto full) {
+        if constexpr (A16) hb_g2r<AL, decltype(full)::value>(p.A, p.lda, m0, p.M, k0, kend, tid, sa);
+        else h_g2r<AL, decltype(full)::value>(p.A, p.lda, m0, p.M, k0, kend, tid, sa);
+    };
+    auto load_b = [&](int k0, auto full) {
+        if constexpr (B16) hb_g2r<BL, decltype(full)::value>(p.B, p.ldb, n0, p.N, k0, kend, tid, sb);
+        else h_g2r<BL, decltype(full)::value>(p.B, p.ldb, n0, p.N, k0, kend, tid, sb);
+    };
+    auto publish = [&](__bf16* As, __bf16* Bs) {
+        if constexpr (A16) hb_r2s<AL>(As, tid, sa); else h_r2s<AL>(As, tid, sa);
+        if constexpr (B16) hb_r2s<BL>(Bs, tid, sb); else h_r2s<BL>(Bs, tid, sb);
+    };
     if (nk > 0) {
-        h_g2r<AL, false>(p.A, p.lda, m0, p.M, kbeg, kend, tid, sa);
-        h_g2r<BL, false>(p.B, p.ldb, n0, p.N, kbeg, kend, tid, sb);
-        h_r2s<AL>(smem[0][0], tid, sa);
-        h_r2s<BL>(smem[0][1], tid, sb);
+        load_a(kbeg, std::false_type{});
+        load_b(kbeg, std::false_type{});
+        publish(smem[0][0], smem[0][1]);
     }
     __syncthreads();
 
@@ -152,20 +202,17 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_mfma(const GemmArgs p) {
         const bool more = t + 1 < nk;
         if (more) {
             if (k1 + HBK <= kend) {      // the next tile is a full one: no predicates
-                h_g2r<AL, true>(p.A, p.lda, m0, p.M, k1, kend, tid, sa);
-                h_g2r<BL, true>(p.B, p.ldb, n0, p.N, k1, kend, tid, sb);
+                load_a(k1, std::true_type{});
+                load_b(k1, std::true_type{});
             } else {
-                h_g2r<AL, false>(p.A, p.lda, m0, p.M, k1, kend, tid, sa);
-                h_g2r<BL, false>(p.B, p.ldb, n0, p.N, k1, kend, tid, sb);
+                load_a(k1, std::false_type{});
+                load_b(k1, std::false_type{});
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         tile_mma(smem[cur][0], smem[cur][1]);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            h_r2s<AL>(smem[cur ^ 1][0], tid, sa);
-            h_r2s<BL>(smem[cur ^ 1][1], tid, sb);
-        }
+        if (more) publish(smem[cur ^ 1][0], smem[cur ^ 1][1]);
         __syncthreads();
     }
 

@@ -45,6 +45,10 @@ struct GemmArgs {
     float* amax_out;            // null, or where max |stored C| is folded in (EPI_RELU_STATS, EPI_RELU_AFFINE, EPI_BNBWD)
     // A operand stored as fp16 pairs with one power-of-two scale per 128 x 128 block (pairs.h): a_sc[row tile][a_scn]
     const float* a_sc; int a_scn;
+    // hidden activations / gradients stored as bf16 (the bf16 mode's storage format; leading dimensions then count bf16
+    // elements): the output C, and the add-in R together with the BatchNorm input bn_y.  Staged epilogue only.
+    int c_bf16, r_bf16;
+    int a_bf16, b_bf16;         // the A / B operand holds bf16 values (bf16 mode only)
     int* guard;                 // two-piece mode: this product's entry of the guard flags ([0] range, [1] non-finite), or null
     int guard_log2;             // threshold of the range test
     int a_vec, b_vec;
@@ -237,7 +241,6 @@ constexpr int EPL = 132;
 
 __device__ __forceinline__ float4 ld4(const float* q) { return *reinterpret_cast<const float4*>(q); }
 __device__ __forceinline__ void st4(float* q, const float4 v) { *reinterpret_cast<float4*>(q) = v; }
-
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[2][2], float* lds, int m0, int n0, int tile_m, int zz) {
     const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
@@ -344,11 +347,11 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             }
             if (USE_Y) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) yq[j] = ld4(p.bn_y + (size_t)rowc[j] * p.ldc + colc);
+                for (int j = 0; j < 8; ++j) yq[j] = ld4x(p.bn_y, (size_t)rowc[j] * p.ldc + colc, p.r_bf16);
             }
             if (USE_R && p.R) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) rq[j] = ld4(p.R + (size_t)rowc[j] * p.ldr + colc);
+                for (int j = 0; j < 8; ++j) rq[j] = ld4x(p.R, (size_t)rowc[j] * p.ldr + colc, p.r_bf16);
             }
             if (USE_E) {
 #pragma unroll
@@ -364,12 +367,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             const size_t o = (size_t)row * p.ldc + col;
             if (USE_R && p.R) { const float4 q = rq[j]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
             if (EPI == EPI_PLAIN || EPI == EPI_BIAS) {
-                st4(Cz + o, v);
+                st4x(Cz, o, v, p.c_bf16);
             } else if (EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE) {
-                st4(Cz + o, v);
+                st4x(Cz, o, v, p.c_bf16);
                 vmax = amax4(vmax, v);
             } else if (EPI == EPI_GSTATS) {
-                st4(Cz + o, v);
+                st4x(Cz, o, v, p.c_bf16);
                 const float4 y = yq[j];
                 bsb[0] += v.x; bsb[1] += v.y; bsb[2] += v.z; bsb[3] += v.w;
                 bk0[0] = fmaf(v.x, (y.x - bmu[0]) * bis[0], bk0[0]); bk0[1] = fmaf(v.y, (y.y - bmu[1]) * bis[1], bk0[1]);
@@ -381,7 +384,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
                 d.y = y.y > 0.f ? bk0[1] * v.y - bk1[1] - bk2[1] * ((y.y - bmu[1]) * bis[1]) : 0.f;
                 d.z = y.z > 0.f ? bk0[2] * v.z - bk1[2] - bk2[2] * ((y.z - bmu[2]) * bis[2]) : 0.f;
                 d.w = y.w > 0.f ? bk0[3] * v.w - bk1[3] - bk2[3] * ((y.w - bmu[3]) * bis[3]) : 0.f;
-                st4(Cz + o, d);
+                st4x(Cz, o, d, p.c_bf16);
                 vmax = amax4(vmax, d);
                 bsb[0] += d.x; bsb[1] += d.y; bsb[2] += d.z; bsb[3] += d.w;
             } else if (EPI == EPI_MUL) {
@@ -410,6 +413,14 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
                 if (p.C3) st4(p.C3 + o, make_float4(val[0] * val[0], val[1] * val[1], val[2] * val[2], val[3] * val[3]));
             }
         };
+        if (p.c_bf16 && col >= p.N && col < p.ldc) {     // pad columns of a bf16 row: zeros (consumers copy whole 64-byte row pieces)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int lr = (tid >> 5) + 8 * j;
+                const int row = m0 + (lr >> 5) * 64 + rb * 32 + (lr & 31);
+                if (row < p.M) st4x(Cz, (size_t)row * p.ldc + col, make_float4(0.f, 0.f, 0.f, 0.f), 1);
+            }
+        }
         if (col < p.N) {                               // N % 4 == 0 on this path: a 4-column group is in or out as a whole
             if (m0 + BM <= p.M) {                      // interior row tile (uniform): no per-row checks
 #pragma unroll

@@ -41,7 +41,11 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 }
 
 // NG groups of four waves (block tile 128 NG x 256), QNST stages in the ring.
-template <int EPI, int NG>
+// FMT 0: pair format, 16 k per stage (a row's 64-byte piece = high and low fp16 pieces of 16 k), three f16 MFMAs per
+// product.  FMT 1: both operands are plain bf16 matrices (A row-major with a pitch of p.lda bf16 elements, B pre-imaged by
+// btvae_weight_image_bf16), 32 k per stage (the 64-byte piece = 32 k), one bf16 MFMA per product; pieces 0, 1 are the
+// operands of the first 16-k step, pieces 2, 3 of the second -- the addressing of the pair format's p and q pieces.
+template <int EPI, int NG, int FMT = 0>
 __global__ __launch_bounds__(256 * NG, 2) void gemm_pq256(const GemmArgs p) {
     constexpr int QM = 128 * NG, QST_A = QM * QROW, QSTAGE = QST_A + QST_B;
     constexpr int QNST = NG == 2 ? 4 : 3;                  // 128 KiB (one workgroup per CU) / 72 KiB (two)
@@ -57,13 +61,13 @@ __global__ __launch_bounds__(256 * NG, 2) void gemm_pq256(const GemmArgs p) {
     const int bid = wg_tile(p, zz);
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int m0 = tile_m * QM, n0 = tile_n * QN;
-    const int nk = (p.K + 15) >> 4;
+    const int nk = FMT ? (p.K + 31) >> 5 : (p.K + 15) >> 4;
 
     // ---- DMA sources: per stage this wave moves rows 32 wid .. + 31 of the A image (two pieces of 16 rows x 64 B, each
     // lane one 16-byte piece; the row's pieces are permuted on the source side so that the image is swizzled) and 2 KiB
     // of the B block, which is stored as its image.
     const char* Ab = reinterpret_cast<const char*>(p.A);
-    const size_t pitch = (size_t)p.lda * 4;
+    const size_t pitch = (size_t)p.lda * (FMT ? 2 : 4);
     const char* asrc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -102,8 +106,8 @@ __global__ __launch_bounds__(256 * NG, 2) void gemm_pq256(const GemmArgs p) {
                 for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
 
     // block scales of this group's 128 rows; the accumulators are kept in units of the current 128-k block's scale
-    const float* asc = p.a_sc + (size_t)(tile_m * NG + g) * p.a_scn;
-    const bool rows_in = m0 + g * 128 < p.M;               // a group wholly past the matrix has no scales of its own
+    const float* asc = FMT ? nullptr : p.a_sc + (size_t)(tile_m * NG + g) * p.a_scn;
+    const bool rows_in = !FMT && m0 + g * 128 < p.M;       // a group wholly past the matrix has no scales of its own
     float sc_a = rows_in ? asc[0] : 1.f;
 
 #pragma unroll
@@ -150,12 +154,20 @@ __global__ __launch_bounds__(256 * NG, 2) void gemm_pq256(const GemmArgs p) {
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                if constexpr (FMT == 1) {
+                    typedef __bf16 qb16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[h][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[i], bp[j], acc[h][i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[h][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(qb16x8, ap[i]), __builtin_bit_cast(qb16x8, bp[j]), acc[h][i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[h][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[i], bq[j], acc[h][i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[h][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(qb16x8, aq[i]), __builtin_bit_cast(qb16x8, bq[j]), acc[h][i][j], 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[h][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[i], bp[j], acc[h][i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[h][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[i], bp[j], acc[h][i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[h][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[i], bq[j], acc[h][i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[h][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[i], bp[j], acc[h][i][j], 0, 0, 0);
+                }
             }
         }
         if ((t & 7) == 7 && t + 1 < nk && rows_in) {       // next stage starts a new scale block
@@ -189,18 +201,20 @@ __global__ __launch_bounds__(256 * NG, 2) void gemm_pq256(const GemmArgs p) {
         return;
     }
 #endif
-    const float ia = btvae_pairs::pq_inv(sc_a), ib = btvae_pairs::pq_inv(btvae_pairs::pq_scale_for(*p.amax_b));
+    const float ia = btvae_pairs::pq_inv(sc_a), ib = FMT ? 1.f : btvae_pairs::pq_inv(btvae_pairs::pq_scale_for(*p.amax_b));
     float* lds = reinterpret_cast<float*>(smem + g * QEPI);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (n0 + h * BN >= p.N) break;                     // uniform over the workgroup
         if (h > 0) __syncthreads();
+        if constexpr (FMT == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[h][i][j][e] = (acc[h][i][j][e] * ia) * ib;
+                    for (int e = 0; e < 16; ++e) acc[h][i][j][e] = (acc[h][i][j][e] * ia) * ib;
+        }
         gemm_epilogue<EPI>(p, acc[h], lds, m0 + g * 128, n0 + h * BN, tile_m * NG + g, zz);
     }
 }

@@ -191,7 +191,33 @@ PITCHED_ROWS = not os.environ.get('BTVAE_NO_PITCHED_ROWS')    # hidden activatio
 PRESPLIT_WEIGHTS = not os.environ.get('BTVAE_NO_PRESPLIT')   # split mode: weights split into bf16 planes once per pass
 
 
+HIDDEN_BF16 = not os.environ.get('BTVAE_NO_BF16_STORAGE')   # bf16 mode: hidden activations and gradients are stored as bf16
+
+
 PLANES_FWD, PLANES_DX = 1, 2
+
+
+def _hidden_bf16() -> bool:
+    """bf16 mode: the [rows, hidden width] activations and gradients between the Linear layers live in HBM as bf16 --
+    the values the bf16 products multiply anyway -- so every kernel that touches them moves half the bytes, and the
+    hidden-layer products copy them global -> LDS without converting.  Network inputs, head outputs, weights, statistics
+    and every reduction stay fp32."""
+    return HIDDEN_BF16 and nv.lib().btvae_get_gemm_precision() == 1
+
+
+def _is16(t) -> bool:
+    return t is not None and t.dtype == torch.bfloat16
+
+
+def _bf16(a=None, out=None, aux=(), b=None):
+    """Tell the next launch which of its matrices are stored as bf16 (``btvae_next_bf16``): the A operand, the output,
+    the add-in / BatchNorm input (which must agree), a weight gradient's B operand."""
+    aux = [t for t in aux if t is not None]
+    if aux and len({t.dtype for t in aux}) != 1:
+        raise RuntimeError("the add-in and the BatchNorm input of one launch disagree on their storage type")
+    m = (1 if _is16(a) else 0) | (2 if _is16(out) else 0) | (4 if aux and _is16(aux[0]) else 0) | (8 if _is16(b) else 0)
+    if m:
+        nv.lib().btvae_next_bf16(m)
 
 
 def _split_mode() -> int:
@@ -350,11 +376,24 @@ def _planes_amax(planes: Optional[torch.Tensor], W: torch.Tensor) -> Optional[to
     return _amax(W)
 
 
+def _weight_image_bf16(W: torch.Tensor, which: int) -> Optional[torch.Tensor]:
+    """bf16 storage mode: the stage images of ``W`` [N, K] for the 256-wide products on bf16-stored activations
+    (``btvae_weight_image_bf16``): the forward image when the layer reads a hidden activation (K is the hidden width), the
+    dX image when it writes one... a product whose image is missing runs the 128-wide kernel on the fp32 weight."""
+    N, K = W.shape
+    L = nv.lib()
+    img = torch.empty(L.btvae_weight_image_bf16_bytes(N, K, 0) + L.btvae_weight_image_bf16_bytes(N, K, 1), dtype=torch.uint8, device=W.device)
+    nv.call("btvae_weight_image_bf16", P(W), K, N, K, which, P(img))
+    return img
+
+
 def _weight_planes(W: torch.Tensor, which: int) -> Optional[torch.Tensor]:
     """bf16 planes of a weight matrix for the ``*_pw`` products (``btvae_weight_planes``; ``which``: the forward image,
     the dX image or both), or None outside the split mode.  They are a copy of ``W`` as it is now: made per forward
     pass, used by that pass and its backward."""
     mode = _split_mode()
+    if _hidden_bf16():
+        return _weight_image_bf16(W, which)
     if not PRESPLIT_WEIGHTS or not mode:
         return None
     N, K = W.shape
@@ -372,7 +411,8 @@ def _plan_planes(plan: "NetPlan", backward: bool) -> Dict[torch.nn.Linear, torch
     pass: hidden Linears get the forward image (+ the dX image when a backward follows), head output Linears the dX
     image only (their forward kernel reads the fp32 weight).  Empty outside the split mode."""
     mode = _split_mode()
-    if not PRESPLIT_WEIGHTS or not mode:
+    bf = _hidden_bf16()
+    if not bf and (not PRESPLIT_WEIGHTS or not mode):
         return {}
     items = [(u.lin, PLANES_FWD | (PLANES_DX if backward else 0)) for u in plan.trunk]
     for units in plan.heads.values():
@@ -380,6 +420,21 @@ def _plan_planes(plan: "NetPlan", backward: bool) -> Dict[torch.nn.Linear, torch
         if backward:
             items.append((units[-1].lin, PLANES_DX))
     L = nv.lib()
+    if bf:
+        # stage images for the 256-wide products: only layers that read or write a hidden activation in whole 64-byte row
+        # pieces need them; the others' products read the fp32 weight
+        sizes = [L.btvae_weight_image_bf16_bytes(lin.out_features, lin.in_features, 0) + L.btvae_weight_image_bf16_bytes(lin.out_features, lin.in_features, 1)
+                 for lin, _ in items]
+        buf = torch.empty(sum(sizes), dtype=torch.uint8, device=items[0][0].weight.device)
+        out, off = {}, 0
+        for (lin, _), n in zip(items, sizes):
+            out[lin] = buf[off:off + n]       # sizes are multiples of 16 KiB
+            off += n
+        cnt = len(items)
+        PtrArr, IntArr = nv.c_void_p * cnt, nv.ctypes.c_int * cnt
+        nv.call("btvae_weight_image_bf16_multi", PtrArr(*[lin.weight.data_ptr() for lin, _ in items]), IntArr(*[lin.out_features for lin, _ in items]),
+                IntArr(*[lin.in_features for lin, _ in items]), PtrArr(*[out[lin].data_ptr() for lin, _ in items]), IntArr(*[w for _, w in items]), cnt)
+        return out
     sizes = [L.btvae_weight_planes_elems(lin.out_features, lin.in_features) for lin, _ in items]
     buf = torch.empty(sum(sizes), dtype=torch.int16, device=items[0][0].weight.device)
     out, off = {}, 0
@@ -414,6 +469,11 @@ def _rows_on_lines(M: int, N: int, dev, on: Optional[bool] = None) -> torch.Tens
     such a matrix is told its pitch: a leading-dimension argument where the entry point has one, ``_pitches`` otherwise.
     The pitch is a function of the width, so all [M, N] matrices of one call share it."""
     pitch = -(-N // ROW_LINE_FLOATS) * ROW_LINE_FLOATS
+    if on is None and N % 8 == 0 and _hidden_bf16():
+        # bf16 storage: the pitch is a multiple of 32 elements whatever PITCHED_ROWS says (the hidden-layer products copy
+        # whole 64-byte pieces of a row; the producers keep the pad columns at zero)
+        t = torch.empty(M, pitch, device=dev, dtype=torch.bfloat16)
+        return t if pitch == N else t[:, :N]
     if pitch == N or not (PITCHED_ROWS if on is None else on):
         return torch.empty(M, N, device=dev)
     return torch.empty(M, pitch, device=dev)[:, :N]
@@ -423,8 +483,8 @@ def _rows_like(ref: torch.Tensor) -> torch.Tensor:
     """An uninitialised matrix of ``ref``'s shape and row pitch."""
     M, N = ref.shape
     if ref.stride(0) == N:
-        return torch.empty(M, N, device=ref.device)
-    return torch.empty(M, ref.stride(0), device=ref.device)[:, :N]
+        return torch.empty(M, N, device=ref.device, dtype=ref.dtype)
+    return torch.empty(M, ref.stride(0), device=ref.device, dtype=ref.dtype)[:, :N]
 
 
 def _pitches(n: Optional[torch.Tensor] = None, k: Optional[torch.Tensor] = None, same_n=(), same_k=()):
@@ -444,9 +504,11 @@ def _pitches(n: Optional[torch.Tensor] = None, k: Optional[torch.Tensor] = None,
 def _like_rows(t: Optional[torch.Tensor], ref: torch.Tensor) -> Optional[torch.Tensor]:
     """``t`` with the row pitch of ``ref`` (same shape): itself when it has it, else a copy (an input of the network that
     a residual unit adds to a padded activation)."""
-    if t is None or t.stride(0) == ref.stride(0):
+    if t is None or (t.stride(0) == ref.stride(0) and t.dtype == ref.dtype):
         return t
     out = _rows_like(ref)
+    if out.stride(0) != out.shape[1] and _is16(out):
+        out.as_strided((out.shape[0], out.stride(0)), (out.stride(0), 1)).zero_()     # pad columns of a bf16 row stay zero
     out.copy_(t)
     if getattr(t, "_btvae_amax", None) is not None:
         out._btvae_amax = t._btvae_amax
@@ -505,6 +567,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         _operand_maxima(_amax(x), _planes_amax(wp, W), (id(u.lin.weight), "fwd"))
         _track_output(y)
         _pitches(n=y)
+        _bf16(a=x, out=y)
         nv.call("btvae_linear_relu_stats_fwd_pw", PR(x), x.stride(0), P(W), P(wp), P(b), PR(y), P(part), M, K, N)
         mean, invstd = torch.empty(N, device=dev), torch.empty(N, device=dev)
         track = u.bn.track_running_stats and u.bn.running_mean is not None
@@ -535,6 +598,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         res_in = _like_rows(x, y) if u.residual else None
         _track_output(out)
         _pitches(n=y, same_n=(res_in, out))
+        _bf16(out=out)
         nv.call("btvae_bn_apply_fwd", PR(y), P(mean), P(invstd), P(u.bn.weight), P(u.bn.bias), PR(res_in),
                 P(keep), ks, PR(out), M, N)
         if saved is not None and keep is None:
@@ -544,6 +608,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         y = _rows_on_lines(M, N, dev)
         _operand_maxima(_amax(x), _planes_amax(wp, W), (id(u.lin.weight), "fwd"))
         _track_output(y)
+        _bf16(a=x, out=y)
         nv.call("btvae_linear_relu_affine_fwd_pw_ld", PR(x), x.stride(0), P(W), P(wp), P(b), None, None, None, 0, PR(y), y.stride(0), M, K, N)
         keep, ks = None, 1.0
         if u.dropout_p > 0.0:
@@ -553,6 +618,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
             res_in = _like_rows(x, y) if u.residual else None
             _track_output(out)
             _pitches(n=y, same_n=(res_in, out))
+            _bf16(out=out)
             nv.call("btvae_bn_apply_fwd", PR(y), None, None, None, None, PR(res_in), P(keep), ks, PR(out), M, N)
         else:
             out = y
@@ -566,6 +632,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
             nv.call("btvae_bn_fold_eval", P(u.bn.weight), P(u.bn.bias), P(u.bn.running_mean), P(u.bn.running_var), float(u.bn.eps), P(scale), P(shift), N)
         _operand_maxima(_amax(x), _planes_amax(wp, W), (id(u.lin.weight), "fwd"))
         _track_output(out)
+        _bf16(a=x, out=out, aux=(x if u.residual else None,))
         nv.call("btvae_linear_relu_affine_fwd_pw_ld", PR(x), x.stride(0), P(W), P(wp), P(b), P(scale), P(shift),
                 PR(x) if u.residual else None, x.stride(0), PR(out), out.stride(0), M, K, N)
     return out
@@ -588,9 +655,10 @@ def head_forward(u: Unit, x, act: int, lo: float, hi: float, want_dfac: bool, wa
     val = torch.empty(M, N, device=dev)
     dfac = torch.empty(M, N, device=dev) if want_dfac else None
     sq = torch.empty(M, N, device=dev) if want_sq else None
-    ws = WS.get("headslab", HEAD_WS_FLOATS, dev) if M <= 128 * 128 else None      # few row tiles: split reduction (see the C side)
+    ws = WS.get("headslab", HEAD_WS_FLOATS, dev) if (M <= 128 * 128 and not _is16(a)) else None      # few row tiles: split reduction (see the C side)
     if N > 64 and ws is None:                 # the 128-wide head kernel has a two-piece form; the narrow one (N <= 64) is
         _operand_maxima(_amax(a), _amax(W), (id(u.lin.weight), "fwd"))   # memory-bound and the split-reduction one latency-bound
+    _bf16(a=a)
     nv.call("btvae_linear_head_fwd_ws", PR(a), a.stride(0), P(W), P(b), act, float(lo), float(hi), P(val), P(dfac), P(sq),
             P(ws), ws.numel() if ws is not None else 0, M, K, N)
     own = planes.get(u.lin) if planes else None
@@ -659,6 +727,7 @@ def _wgrad(lin: torch.nn.Linear, dy: torch.Tensor, x: torch.Tensor, x_scale, x_s
     ws = WS.get("wgrad", WGRAD_WS_FLOATS, dy.device)
     _operand_maxima(_amax(dy), _amax(x), (id(lin.weight), "wgrad"))
     _pitches(n=dy)
+    _bf16(a=dy, b=x)
     if x_scale is None:
         nv.call("btvae_linear_wgrad", PR(dy), PR(x), x.stride(0), P(_grad_view(lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
     elif products is not None and BWD_SUMS_FROM_CONSUMERS:
@@ -699,6 +768,7 @@ def _dgrad_with_producer_backward(pr: BwdProducts, dy: torch.Tensor, W: torch.Te
     _operand_maxima(_amax(dy), _planes_amax(planes, W), (id(W), "dgrad"))
     _track_output(dpre)
     _pitches(n=dy, k=dpre, same_k=(r, sv_p.y))
+    _bf16(a=dy, out=dpre, aux=(r, sv_p.y))
     nv.call("btvae_linear_dgrad_bnbwd_pw", PR(dy), P(W), P(planes), PR(r), PR(sv_p.y), P(sv_p.mean), P(sv_p.invstd), P(u_p.bn.weight), P(sums),
             int(max(sv_p.total_rows, M)), PR(dpre), P(part), M, N, Np)
     db_cur = torch.empty(Np, device=dev) if sv_p.x_scale is not None else None
@@ -729,6 +799,7 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
     elif u.bn is None:
         _track_output(dpre)
         _pitches(n=sv.y, same_n=(g, dpre))
+        _bf16(out=dpre)
         nv.call("btvae_relu_bwd", PR(g), PR(sv.y), P(sv.keep), float(sv.keep_scale), P(_grad_view(u.lin.bias)), P(db_cur), PR(dpre), P(scr), M, N, int(accumulate))
     elif pr is not None and pr.consumers > 0 and pr.filled == pr.consumers and sv.keep is None:
         # every reader of this unit's output was a folded Linear whose weight gradient has run: the column sums of
@@ -740,6 +811,7 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
             BN_SYNC.sum_(sums)
         _track_output(dpre)
         _pitches(n=sv.y, same_n=(g, dpre))
+        _bf16(out=dpre)
         nv.call("btvae_bn_relu_bwd_apply", PR(g), PR(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), None, 1.0,
                 P(sums), int(max(sv.total_rows, M)), P(_grad_view(u.lin.bias)), P(db_cur), PR(dpre), P(scr), M, N, int(accumulate))
     elif sv.g_partials is not None:
@@ -751,22 +823,26 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
             BN_SYNC.sum_(sums)
         _track_output(dpre)
         _pitches(n=sv.y, same_n=(g, dpre))
+        _bf16(out=dpre)
         nv.call("btvae_bn_relu_bwd_apply", PR(g), PR(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), None, 1.0,
                 P(sums), int(max(sv.total_rows, M)), P(_grad_view(u.lin.bias)), P(db_cur), PR(dpre), P(scr), M, N, int(accumulate))
     elif sv.synced:
         # statistics span ranks: local column sums -> sum over ranks -> dPre with the batch-wide sums
         sums = torch.empty(2, N, device=dev)
         _pitches(n=sv.y, same_n=(g,))
+        _bf16(a=g)
         nv.call("btvae_bn_relu_bwd_sums", PR(g), PR(sv.y), P(sv.mean), P(sv.invstd), P(sv.keep), float(sv.keep_scale),
                 P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)), P(sums), P(scr), M, N, int(accumulate))
         BN_SYNC.sum_(sums)
         _track_output(dpre)
         _pitches(n=sv.y, same_n=(g, dpre))
+        _bf16(out=dpre)
         nv.call("btvae_bn_relu_bwd_apply", PR(g), PR(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
                 P(sums), int(sv.total_rows), P(_grad_view(u.lin.bias)), P(db_cur), PR(dpre), P(scr), M, N, int(accumulate))
     else:
         _track_output(dpre)
         _pitches(n=sv.y, same_n=(g, dpre))
+        _bf16(out=dpre)
         nv.call("btvae_bn_relu_bwd", PR(g), PR(sv.y), P(sv.mean), P(sv.invstd), P(u.bn.weight), P(sv.keep), float(sv.keep_scale),
                 P(_grad_view(u.bn.weight)), P(_grad_view(u.bn.bias)),
                 P(_grad_view(u.lin.bias)), P(db_cur), PR(dpre), P(scr), M, N, int(accumulate))
@@ -793,11 +869,13 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
         part = torch.empty(tiles, 2, K, device=dev)
         _operand_maxima(_amax(dpre), _planes_amax(sv.w_planes, u.lin.weight), (id(u.lin.weight), "dgrad"))
         _pitches(n=dpre, k=dx, same_k=(r, src.y))
+        _bf16(a=dpre, out=dx, aux=(r, src.y))
         nv.call("btvae_linear_dgrad_gstats_pw", PR(dpre), P(u.lin.weight), P(sv.w_planes), PR(r), PR(src.y), P(src.mean), P(src.invstd), PR(dx), P(part), M, N, K)
         src.g_partials = (part, tiles)
     else:
         _operand_maxima(_amax(dpre), _planes_amax(sv.w_planes, u.lin.weight), (id(u.lin.weight), "dgrad"))
         _pitches(n=dpre)
+        _bf16(a=dpre, out=dx, aux=(r,))
         nv.call("btvae_linear_dgrad_pw", PR(dpre), P(u.lin.weight), P(sv.w_planes), PR(r), PR(dx), dx.stride(0), M, N, K)
     return dx
 
@@ -825,6 +903,7 @@ def net_backward(plan: NetPlan, tape: NetTape, draw: Dict[str, torch.Tensor], ne
         else:
             g = _rows_like(t_in)
             _operand_maxima(_amax(d), _planes_amax(tape.head_planes.get(name), last.lin.weight), (id(last.lin.weight), "dgrad"))
+            _bf16(a=d, out=g)
             nv.call("btvae_linear_dgrad_pw", P(d), P(last.lin.weight), P(tape.head_planes.get(name)), None, PR(g), g.stride(0), M, N, K)
         svs = tape.heads[name]
         for i in range(len(units) - 2, -1, -1):

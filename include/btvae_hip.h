@@ -154,6 +154,27 @@ int btvae_matmul_nn_mul(const float* A, int lda, const float* B, int ldb, const 
  * Width-1000 rows that start on 128-byte lines (pitch 1024) make the products that read them 6-11 % faster. */
 int btvae_next_row_pitches(int ld_n, int ld_k);
 
+/* bf16 storage of hidden activations and gradients (mode 1 only; no counterpart in the reference, whose tensors are fp32:
+ * src/submodels.py:28-35).  The [rows, hidden width] matrices between the Linear layers may live in HBM as bf16 -- the
+ * values mode 1 multiplies anyway.  btvae_next_bf16(mask) names which matrices of the NEXT launch from the calling
+ * thread are bf16 (pitches then count bf16 elements): bit 0 the A operand (X of a forward product, dY of a dX or
+ * weight-gradient product), bit 1 the output (Y / Out / dX / dPre), bit 2 the add-in R together with the BatchNorm input
+ * Yb, bit 3 the B operand X of a weight gradient; for btvae_bn_apply_fwd, btvae_bn_relu_bwd*, btvae_relu_bwd any non-zero
+ * mask means all their [M, N] matrices.  Widths must be multiples of 8 (4 for outputs), bases 16-byte aligned.  Producers
+ * write zeros into the pad columns between the width and the pitch.
+ * A forward / dX product whose A operand is bf16 with a pitch that is a multiple of 32 and whose Wplanes argument holds
+ * the weight's stage images (btvae_weight_image_bf16: forward image at the start, dX image
+ * btvae_weight_image_bf16_bytes(N, K, 0) bytes further; `which` 1 / 2 / 3 as for btvae_weight_planes; buffer of
+ * _bytes(N, K, 0) + _bytes(N, K, 1) bytes, 16-byte aligned) runs on a 256-wide kernel that copies both operands
+ * global -> LDS by DMA (633 TFLOP/s at M = 65536, N = K = 1000 against 360 for fp32 tensors); without images the
+ * 128-wide kernel reads the fp32 weight. */
+int btvae_next_bf16(int mask);
+long long btvae_weight_image_bf16_bytes(int N, int K, int transpose);
+int btvae_weight_image_bf16(const float* W, int ldw, int N, int K, int which, void* image, void* stream);
+/* The same for `count` contiguous matrices (host arrays of length count) in one launch per 32 images. */
+int btvae_weight_image_bf16_multi(const float* const* W, const int* N, const int* K, void* const* image, const int* which,
+                                  int count, void* stream);
+
 /* ---- BatchNorm1d (torch.nn.BatchNorm1d as used at src/submodels.py:20-21,50) ---- */
 int btvae_strip_chunks(int M);
 /* Merge the GEMM's per-tile partials: mean, invstd = 1/sqrt(biased var + eps); running buffers (may both be
