@@ -1035,6 +1035,144 @@ def test_linear_products_bf16_operands(dev, M, N, K):
         assert torch.allclose(part[t, 1].cpu().double(), ((blk - blk.mean(0)) ** 2).sum(0), rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("M,H", [(300, 200), (520, 72), (16500, 1000)])
+def test_bf16_stored_hidden_matrices(dev, M, H):
+    """bf16 mode with the hidden matrices stored as bf16 (``btvae_next_bf16``): every kernel that reads or writes such a
+    matrix against fp64 on the bf16 values it was given -- the forward, eval-mode forward, dX (plain, with the BatchNorm
+    backward sums, with the fused BatchNorm backward) and weight-gradient products, with the weight's stage images (the
+    256-wide DMA-fed kernel: 128-row workgroups, and 256-row ones at M = 16,500) and without (the 128-wide kernel); the
+    head forward; the BatchNorm apply / backward kernels.  Outputs are bf16: compared to half a unit in the last place of
+    bf16 (2^-8 relative) plus the fp32 accumulation error; pad columns of every output row are written as zeros."""
+    L = nv.lib()
+    g = torch.Generator().manual_seed(M + H)
+    ld = (H + 31) // 32 * 32
+    K0, V = 52, 100
+    A, OUT, AUX, B = 1, 2, 4, 8
+
+    def hid(t):                                   # fp32 [M, H] -> bf16 matrix of pitch ld, pad columns zero
+        buf = torch.zeros(t.shape[0], ld, dtype=torch.bfloat16, device=dev)
+        buf[:, :H] = t.to(dev)
+        return buf
+
+    def out16():                                  # an output buffer whose pad columns must come back as zeros
+        return torch.full((M, ld), float("nan"), dtype=torch.bfloat16, device=dev)
+
+    def check(got16, ref, what, extra=0.0):
+        got = got16[:, :H].double().cpu()
+        lim = 2.0 ** -8 * ref.abs() + 1e-5 * ref.abs().max() + extra
+        assert ((got - ref).abs() <= lim).all(), (what, float(((got - ref).abs() - lim).max()))
+        if ld > H:
+            assert bool((got16[:, H:] == 0).all()), what + ": pad columns"
+
+    X = torch.randn(M, H, generator=g).clamp_(min=0); W = torch.randn(H, H, generator=g) * (1.0 / H ** 0.5); b = torch.randn(H, generator=g) * 0.1
+    Xb = hid(X); Xr = Xb[:, :H].double().cpu(); Wr = W.to(torch.bfloat16).double()
+    Wd, bd = W.to(dev), b.to(dev)
+    tiles = (M + 127) // 128
+    part, part2 = torch.empty(tiles, 2, H, device=dev), torch.empty(tiles, 2, H, device=dev)
+    img = torch.empty(L.btvae_weight_image_bf16_bytes(H, H, 0) + L.btvae_weight_image_bf16_bytes(H, H, 1), dtype=torch.uint8, device=dev)
+    nv.set_gemm_precision("bf16")
+    try:
+        nv.call("btvae_weight_image_bf16", P(Wd), H, H, H, 3, P(img))
+        # ---- forward: relu(X W^T + b) with column statistics
+        ref = torch.relu(Xr @ Wr.t() + b.double())
+        for planes, pt in ((img, part), (None, part2)):
+            Y = out16()
+            L.btvae_next_row_pitches(ld, 0); L.btvae_next_bf16(A | OUT)
+            nv.call("btvae_linear_relu_stats_fwd_pw", P(Xb), ld, P(Wd), P(planes), P(bd), P(Y), P(pt), M, H, H)
+            check(Y, ref, "forward" + (" (images)" if planes is not None else ""))
+        assert torch.allclose(part, part2, rtol=1e-4, atol=1e-5)          # the statistics are taken before the rounding
+        t0 = ref[:128]
+        assert torch.allclose(part[0, 0].double().cpu(), t0.mean(0), rtol=1e-3, atol=1e-4)
+        # ---- a first layer: fp32 input, bf16 output
+        X0 = torch.randn(M, K0, generator=g); W0 = torch.randn(H, K0, generator=g) * 0.2
+        X0d, W0d = X0.to(dev), W0.to(dev)
+        Y = out16()
+        L.btvae_next_row_pitches(ld, 0); L.btvae_next_bf16(OUT)
+        nv.call("btvae_linear_relu_stats_fwd", P(X0d), K0, P(W0d), P(bd), P(Y), P(part2), M, K0, H)
+        check(Y, torch.relu(X0.to(torch.bfloat16).double() @ W0.to(torch.bfloat16).double().t() + b.double()), "first layer")
+        # ---- eval mode: relu(.) * scale + shift + X
+        sc, sh = (1 + 0.2 * torch.randn(H, generator=g)), 0.1 * torch.randn(H, generator=g)
+        scd, shd = sc.to(dev), sh.to(dev)
+        ref = torch.relu(Xr @ Wr.t() + b.double()) * sc.double() + sh.double() + Xr
+        for planes in (img, None):
+            Y = out16()
+            L.btvae_next_bf16(A | OUT | AUX)
+            nv.call("btvae_linear_relu_affine_fwd_pw_ld", P(Xb), ld, P(Wd), P(planes), P(bd), P(scd), P(shd), P(Xb), ld, P(Y), ld, M, H, H)
+            check(Y, ref, "eval forward")
+        # ---- dX products: G = dY W (+ R)
+        dY = torch.randn(M, H, generator=g); R = torch.randn(M, H, generator=g)
+        dYb, Rb = hid(dY), hid(R)
+        dYr, Rr = dYb[:, :H].double().cpu(), Rb[:, :H].double().cpu()
+        Gref = dYr @ Wr + Rr
+        for planes in (img, None):
+            G = out16()
+            L.btvae_next_row_pitches(ld, 0); L.btvae_next_bf16(A | OUT | AUX)
+            nv.call("btvae_linear_dgrad_pw", P(dYb), P(Wd), P(planes), P(Rb), P(G), ld, M, H, H)
+            check(G, Gref, "dgrad")
+        mean, inv = Xr.mean(0), 1 / torch.sqrt(Xr.var(0, unbiased=False) + 1e-5)
+        gam = 1 + 0.3 * torch.randn(H, generator=g)
+        md, idv, gd = mean.float().to(dev), inv.float().to(dev), gam.to(dev)
+        xhat = (Xr - mean) * inv
+        for planes in (img, None):
+            G = out16()
+            gp = torch.empty(tiles, 2, H, device=dev)
+            L.btvae_next_row_pitches(ld, ld); L.btvae_next_bf16(A | OUT | AUX)
+            nv.call("btvae_linear_dgrad_gstats_pw", P(dYb), P(Wd), P(planes), P(Rb), P(Xb), P(md), P(idv), P(G), P(gp), M, H, H)
+            check(G, Gref, "dgrad + sums")
+            sums = gp.double().cpu().sum(0)
+            assert torch.allclose(sums[0], Gref.sum(0), rtol=2e-3, atol=2e-3 * float(Gref.abs().sum(0).max()))
+            assert torch.allclose(sums[1], (Gref * xhat).sum(0), rtol=2e-3, atol=2e-3 * float((Gref * xhat).abs().sum(0).max()))
+            s2 = torch.stack([Gref.sum(0), (Gref * xhat).sum(0)]).float().to(dev)
+            dP = out16()
+            cp = torch.empty(tiles, H, device=dev)
+            L.btvae_next_row_pitches(ld, ld); L.btvae_next_bf16(A | OUT | AUX)
+            nv.call("btvae_linear_dgrad_bnbwd_pw", P(dYb), P(Wd), P(planes), P(Rb), P(Xb), P(md), P(idv), P(gd), P(s2), M, P(dP), P(cp), M, H, H)
+            gi = (gam.double() * inv)
+            dref = torch.where(Xr > 0, gi * (Gref - s2[0].double().cpu() / M - xhat * s2[1].double().cpu() / M), torch.zeros_like(Gref))
+            check(dP, dref, "dgrad + BatchNorm backward", extra=2.0 ** -8 * float(gi.max()) * Gref.abs())
+        # ---- weight gradients: dW = dY^T X in the three storage combinations
+        ws = torch.empty(8 * 1024 * 1024, device=dev)
+        dW = torch.empty(H, H, device=dev)
+        for a16, b16 in ((True, True), (False, True), (True, False)):
+            da = dYb if a16 else dYb[:, :H].float().contiguous()
+            xb = Xb if b16 else Xb[:, :H].float().contiguous()
+            L.btvae_next_row_pitches(da.stride(0) if a16 else 0, 0); L.btvae_next_bf16((A if a16 else 0) | (B if b16 else 0))
+            nv.call("btvae_linear_wgrad", P(da), P(xb), xb.stride(0), P(dW), P(ws), ws.numel(), M, H, H, 0)
+            ref = dYr.t() @ Xr
+            assert float((dW.double().cpu() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-4, (a16, b16)
+        # ---- head output layer on a bf16 hidden activation
+        Wh, bh = torch.randn(V, H, generator=g) * 0.05, torch.randn(V, generator=g) * 0.1
+        Whd, bhd = Wh.to(dev), bh.to(dev)
+        val, dfac = torch.empty(M, V, device=dev), torch.empty(M, V, device=dev)
+        L.btvae_next_bf16(A)
+        nv.call("btvae_linear_head_fwd", P(Xb), ld, P(Whd), P(bhd), 2, 1e-4, 0.62, P(val), P(dfac), None, M, H, V)
+        ref = torch.relu(Xr @ Wh.to(torch.bfloat16).double().t() + bh.double()).clamp(1e-4, 0.62)
+        assert float((val.double().cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    finally:
+        nv.set_gemm_precision("fp32")
+    # ---- BatchNorm kernels on bf16 matrices (the storage flag is independent of the GEMM mode)
+    beta = 0.1 * torch.randn(H, generator=g)
+    betad = beta.to(dev)
+    Out = out16()
+    L.btvae_next_row_pitches(ld, 0); L.btvae_next_bf16(OUT)
+    nv.call("btvae_bn_apply_fwd", P(Xb), P(md), P(idv), P(gd), P(betad), P(Rb), None, 1.0, P(Out), M, H)
+    check(Out, xhat * gam.double() + beta.double() + Rr, "bn_apply_fwd")
+    scr = torch.empty(L.btvae_bn_relu_bwd_scratch(M, H), device=dev)
+    dg, dbt, dbi = torch.zeros(H, device=dev), torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    dP = out16()
+    L.btvae_next_row_pitches(ld, 0); L.btvae_next_bf16(OUT)
+    nv.call("btvae_bn_relu_bwd", P(dYb), P(Xb), P(md), P(idv), P(gd), None, 1.0, P(dg), P(dbt), P(dbi), None, P(dP), P(scr), M, H, 0)
+    s1, s2 = dYr.sum(0), (dYr * xhat).sum(0)
+    dref = torch.where(Xr > 0, (gam.double() * inv) * (dYr - s1 / M - xhat * s2 / M), torch.zeros_like(dYr))
+    check(dP, dref, "bn_relu_bwd", extra=1e-3 * float(dref.abs().max()))
+    assert torch.allclose(dbt.double().cpu(), s1, rtol=1e-3, atol=1e-3 * float(dYr.abs().sum(0).max()))
+    assert torch.allclose(dg.double().cpu(), s2, rtol=1e-3, atol=1e-3 * float((dYr * xhat).abs().sum(0).max()))
+    dP = out16()
+    L.btvae_next_row_pitches(ld, 0); L.btvae_next_bf16(OUT)
+    nv.call("btvae_relu_bwd", P(dYb), P(Xb), None, 1.0, P(dbi), None, P(dP), P(scr), M, H, 0)
+    check(dP, torch.where(Xr > 0, dYr, torch.zeros_like(dYr)), "relu_bwd")
+
+
 def test_linear_products_at_benchmark_size(dev, gemm_mode):
     """The three Linear products at the benchmark's decoder shape (M = S*B = 65536, N = K = 1000): forward rows and
     dgrad rows sampled against fp64 on the CPU (2e-6 relative + 2e-6*sqrt(reduction length) absolute, as at small
