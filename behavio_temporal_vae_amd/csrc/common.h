@@ -150,6 +150,20 @@ __device__ __forceinline__ void st4x(float* base, size_t i, const float4 v, int 
     const unsigned a = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, b2)), b = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, b2));
     *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + i) = make_uint2(a, b);
 }
+// the same at a byte address: a uniform row base plus a 32-bit lane offset stays `scalar base + one offset register`
+__device__ __forceinline__ float4 ld4b(const char* a, int bf) {
+    if (!bf) return *reinterpret_cast<const float4*>(a);
+    const uint2 u = *reinterpret_cast<const uint2*>(a);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ void st4b(char* a, const float4 v, int bf) {
+    if (!bf) { *reinterpret_cast<float4*>(a) = v; return; }
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 lo = {v.x, v.y}, hi = {v.z, v.w};
+    const unsigned x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, b2)), y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, b2));
+    *reinterpret_cast<uint2*>(a) = make_uint2(x, y);
+}
 
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

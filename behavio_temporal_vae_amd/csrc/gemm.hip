@@ -617,9 +617,11 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     if constexpr (AL == LAY_K && has_bh256<EPI>()) {
         // hidden-layer product on a bf16-stored activation with the weight's stage images: the 256-wide DMA-fed kernel
         // (128-row workgroups while 256-row ones would not fill the chip)
-        if (bf16 && a.a_bf16 && a.Bp && splits == 1 && a.lda % 32 == 0 && a.lda >= (a.K + 31) / 32 * 32) {
+        if (bf16 && a.a_bf16 && a.Bp && splits == 1 && a.lda % 32 == 0 && a.lda >= (a.K + 31) / 32 * 32 && (a.r_bf16 || (!a.R && !a.bn_y))) {
             const int wide_tiles = ((a.M + 255) / 256) * ((a.N + QN - 1) / QN);
             const bool long_epilogue = EPI == EPI_GSTATS || EPI == EPI_BNBWD;      // runs beside a second workgroup's main loop
+            static const int forced = [] { const char* e = getenv("BTVAE_BH256_GROUPS"); return e ? atoi(e) : 0; }();   // tuning: 1 / 2 rows of 128 per workgroup
+            if (forced == 1 || (forced == 2 && wide_tiles >= 256)) return launch_bh256<EPI>(a, forced, s, what);
             return launch_bh256<EPI>(a, (wide_tiles >= 256 && !long_epilogue) ? 2 : 1, s, what);
         }
     }

@@ -96,152 +96,22 @@ __device__ __forceinline__ void head_value(const GemmArgs& p, float raw, float& 
     }
 }
 
-// `red` is LDS scratch of at least 6*128 floats that no wave still reads as a tile.
-// A workgroup of 512 threads runs the epilogue once per group of 256 (each on its own 128 x 128 tile and LDS region), so
-// the thread index used here is the one inside the group.
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x16 (&acc)[2][2], float* red, int m0, int n0, int tile_m, int zz) {
-    const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid >> 1, wc = wid & 1;
-    const int li = lane & 31, lh = lane >> 5;
-    // ---- epilogue: accumulator element r of tile (rb,cb) is row (r&3)+8(r>>2)+4*lh, column li ----
-    float colv[2][3];   // per-column vectors: bias / scale / shift
-    int colg[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int col = n0 + wc * 64 + cb * 32 + li;
-        colg[cb] = col;
-        const bool ok = col < p.N;
-        colv[cb][0] = (EPI == EPI_BIAS || EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE || EPI == EPI_HEAD) && ok && p.bias ? p.bias[col] : 0.f;
-        colv[cb][1] = (EPI == EPI_RELU_AFFINE && ok && p.scale) ? p.scale[col] : 1.f;
-        colv[cb][2] = (EPI == EPI_RELU_AFFINE && ok && p.shift) ? p.shift[col] : 0.f;
-    }
-    float* Cz = p.C + (size_t)zz * p.slab_stride;
-
-    float st_n[2], st_mean[2], st_m2[2];   // EPI_RELU_STATS: this lane's (count, mean, M2) per column block
-    float vmax = 0.f;                      // max |stored value| (EPI_RELU_STATS, EPI_RELU_AFFINE)
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int col = colg[cb];
-        float shiftK = 0.f, s = 0.f, q = 0.f, cnt = 0.f;
-        bool have = false;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const bool ok = row < p.M && col < p.N;
-                float v = acc[rb][cb][r];
-                if (EPI == EPI_PLAIN) {
-                    if (ok) {
-                        if (p.R) v += p.R[(size_t)row * p.ldr + col];
-                        Cz[(size_t)row * p.ldc + col] = v;
-                    }
-                } else if (EPI == EPI_BIAS) {
-                    if (ok) {
-                        v += colv[cb][0];
-                        if (p.R) v += p.R[(size_t)row * p.ldr + col];
-                        Cz[(size_t)row * p.ldc + col] = v;
-                    }
-                } else if (EPI == EPI_RELU_STATS) {
-                    v = fmaxf(v + colv[cb][0], 0.f);
-                    if (ok) {
-                        Cz[(size_t)row * p.ldc + col] = v;
-                        vmax = fmaxf(vmax, v);
-                        if (!have) { shiftK = v; have = true; }
-                        const float d = v - shiftK;
-                        s += d; q += d * d; cnt += 1.f;
-                    }
-                } else if (EPI == EPI_RELU_AFFINE) {
-                    v = fmaxf(v + colv[cb][0], 0.f) * colv[cb][1] + colv[cb][2];
-                    if (ok) {
-                        if (p.R) v += p.R[(size_t)row * p.ldr + col];
-                        Cz[(size_t)row * p.ldc + col] = v;
-                        vmax = fmaxf(vmax, fabsf(v));
-                    }
-                } else if (EPI == EPI_HEAD) {
-                    const float raw = v + colv[cb][0];
-                    float val, df;
-                    if (p.act == 0) {            // clamp
-                        val = fminf(fmaxf(raw, p.lo), p.hi);
-                        df = (raw >= p.lo && raw <= p.hi) ? 1.f : 0.f;
-                    } else if (p.act == 1) {     // clamp(softplus(raw; threshold 5))
-                        const float sp = softplus5(raw);
-                        val = fminf(fmaxf(sp, p.lo), p.hi);
-                        df = (sp >= p.lo && sp <= p.hi) ? (raw > 5.f ? 1.f : 1.f / (1.f + expf(-raw))) : 0.f;
-                    } else {                     // clamp(relu(raw))
-                        const float rl = fmaxf(raw, 0.f);
-                        val = fminf(fmaxf(rl, p.lo), p.hi);
-                        df = (raw > 0.f && rl >= p.lo && rl <= p.hi) ? 1.f : 0.f;
-                    }
-                    if (ok) {
-                        const size_t o = (size_t)row * p.ldc + col;
-                        Cz[o] = val;
-                        if (p.C2) p.C2[o] = df;
-                        if (p.C3) p.C3[o] = val * val;
-                    }
-                } else if (EPI == EPI_MUL) {
-                    if (ok) {
-                        const size_t e = (size_t)row * p.lde + col;
-                        Cz[(size_t)row * p.ldc + col] = v * p.E1[e] * p.E2[e];
-                    }
-                }
-            }
-        }
-        if (EPI == EPI_RELU_STATS) {
-            float mean = 0.f, m2 = 0.f;
-            if (cnt > 0.f) { mean = shiftK + s / cnt; m2 = fmaxf(q - s * s / cnt, 0.f); }
-            // merge the two lane halves (rows +4): Chan's pairwise update
-            const float on = __shfl_xor(cnt, 32, 64), om = __shfl_xor(mean, 32, 64), o2 = __shfl_xor(m2, 32, 64);
-            const float n = cnt + on;
-            if (n > 0.f) {
-                const float dlt = om - mean;
-                m2 = m2 + o2 + dlt * dlt * (cnt * on / n);
-                mean = (cnt * mean + on * om) / n;
-            }
-            st_n[cb] = n; st_mean[cb] = mean; st_m2[cb] = m2;
-        }
-    }
-
-    if (EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE) wave_amax_commit(vmax, p.amax_out);
-    if (EPI == EPI_RELU_STATS) {
-        // red = [wr][3][128]
-        if (lh == 0) {
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int c = wc * 64 + cb * 32 + li;
-                red[(wr * 3 + 0) * 128 + c] = st_n[cb];
-                red[(wr * 3 + 1) * 128 + c] = st_mean[cb];
-                red[(wr * 3 + 2) * 128 + c] = st_m2[cb];
-            }
-        }
-        __syncthreads();
-        if (tid < 128 && n0 + tid < p.N && m0 < p.M) {
-            const float na = red[0 * 128 + tid], ma = red[1 * 128 + tid], qa = red[2 * 128 + tid];
-            const float nb = red[3 * 128 + tid], mb = red[4 * 128 + tid], qb = red[5 * 128 + tid];
-            const float n = na + nb;
-            float mean = ma, m2 = qa;
-            if (nb > 0.f) {
-                const float dlt = mb - ma;
-                m2 = qa + qb + dlt * dlt * (na * nb / n);
-                mean = (na * ma + nb * mb) / n;
-            }
-            p.stats[((size_t)tile_m * 2 + 0) * p.N + n0 + tid] = mean;
-            p.stats[((size_t)tile_m * 2 + 1) * p.N + n0 + tid] = m2;
-        }
-    }
-}
-
-// ---- epilogue staged through LDS ---------------------------------------------------------------------------------
+// ---- epilogue, staged through LDS ----------------------------------------------------------------------------------
 // The accumulator image puts one column per lane, so storing it directly costs 64 four-byte stores per thread (and as
 // many loads for an add-in).  Here each half of the 128x128 tile (the 64 rows of accumulator block rb of both wave
-// rows) goes through a [64][132] fp32 LDS image and leaves as 16-byte accesses: 8 per thread and output.
+// rows) goes through a [64][132] fp32 LDS image and leaves as 16-byte accesses: 8 per thread and output.  Outputs that
+// are not 16-byte addressable (p.c_vec == 0: N or a pitch not a multiple of 4, an unaligned base) leave the same image
+// one element per lane in a rolled loop: rare shapes, and code that must not compete for the kernel's registers.
 // `lds` must hold 64*132 + 6*128 floats (36 KiB) that no wave still reads as a tile.
+// A workgroup of 512 threads runs the epilogue once per group of 256 (each on its own 128 x 128 tile and LDS region), so
+// the thread index used here is the one inside the group.
 constexpr int EPL = 132;
 
 __device__ __forceinline__ float4 ld4(const float* q) { return *reinterpret_cast<const float4*>(q); }
 __device__ __forceinline__ void st4(float* q, const float4 v) { *reinterpret_cast<float4*>(q) = v; }
-template <int EPI>
+// AUX16: the matrices read here (add-in, BatchNorm input) are known to hold bf16 (p.r_bf16 set): they wait for their use
+// in half the registers.
+template <int EPI, bool AUX16 = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[2][2], float* lds, int m0, int n0, int tile_m, int zz) {
     const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
@@ -325,71 +195,134 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
         };
         if (rows_full) to_lds(std::true_type{}); else to_lds(std::false_type{});
         __syncthreads();
-        // LDS image -> global, 16 bytes per lane: thread t handles columns 4*(t&31).. of local rows (t>>5) + 8j.
+        if (!p.c_vec) {                                // uniform
+            if constexpr (EPI != EPI_GSTATS && EPI != EPI_BNBWD) {       // those two are launched on 16-byte addressable outputs only
+#pragma unroll 1
+                for (int i = 0; i < 32; ++i) {
+                    const int il = (tid >> 7) + 2 * i, c = tid & 127;           // image row, column
+                    const int row = m0 + (il >> 5) * 64 + rb * 32 + (il & 31), colx = n0 + c;
+                    if (row < p.M && colx < p.N) {
+                        float v = lds[il * EPL + c];
+                        const size_t o = (size_t)row * p.ldc + colx;
+                        if ((EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_RELU_AFFINE) && p.R) v += p.R[(size_t)row * p.ldr + colx];
+                        if (EPI == EPI_PLAIN || EPI == EPI_BIAS) {
+                            Cz[o] = v;
+                        } else if (EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE) {
+                            Cz[o] = v;
+                            vmax = fmaxf(vmax, fabsf(v));
+                        } else if (EPI == EPI_MUL) {
+                            const size_t e = (size_t)row * p.lde + colx;
+                            Cz[o] = v * p.E1[e] * p.E2[e];
+                        } else if (EPI == EPI_HEAD) {
+                            float val, df;
+                            head_value(p, v, val, df);
+                            Cz[o] = val;
+                            if (p.C2) p.C2[o] = df;
+                            if (p.C3) p.C3[o] = val * val;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            continue;
+        }
+        // LDS image -> global, 16 bytes per lane: thread t handles columns 4*(t&31).. of the tile's rows
+        // lrow(j) = (t>>5) + (a constant of j and rb), j = 0..7.
         // Everything the eight rows need from global memory (add-in, BatchNorm input, multipliers) is loaded first:
         // a load that follows a store in program order cannot be waited for without waiting for the store too (one
         // in-order counter), so loads issued row by row between the stores each cost a full memory round trip.  The
-        // loads are branch-free (rows / columns past the edge read a clamped, valid address): inside per-row
-        // branches the same hoisting is slower than no hoisting.
+        // loads are branch-free (rows / columns past the edge read a clamped, valid address) and nothing is converted
+        // between them: a use of the loaded value there is a wait there.
+        // Every access is `tile base (uniform, 64 bits) + lane offset (32 bits)`: eight rows of three matrices as 64-bit
+        // addresses are 48 registers next to the accumulators, and the compiler computes them all ahead and spills them.
         const int c4 = (tid & 31) << 2;
         const int col = n0 + c4;
+        const int tr = tid >> 5;
+        const int cl = min(c4, p.N - 4 - n0);           // clamped column of the loads, tile-local (N % 4 == 0, n0 < N)
+        const int mlast = p.M - 1 - m0;                 // last valid row of the tile (>= 127 inside the matrix); uniform
+        const int shc = p.c_bf16 ? 1 : 2;
+        auto lrow = [&](int j) { return (j >> 2) * 64 + rb * 32 + 8 * (j & 3) + tr; };
         constexpr bool USE_R = EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_RELU_AFFINE || EPI == EPI_GSTATS || EPI == EPI_BNBWD;
         constexpr bool USE_Y = EPI == EPI_GSTATS || EPI == EPI_BNBWD;
         constexpr bool USE_E = EPI == EPI_MUL;
-        float4 rq[USE_R ? 8 : 1], yq[USE_Y ? 8 : 1], eq1[USE_E ? 8 : 1], eq2[USE_E ? 8 : 1];
-        {
-            const int colc = min(col, p.N - 4);
-            int rowc[8];
+        typedef typename std::conditional<AUX16, uint2, float4>::type aux_t;
+        aux_t rq[8], yq[8];                           // the ones an epilogue does not load are never touched
+        float4 eq1[8], eq2[8];
+        // Row slot j of a matrix with `ld` elements per row, into dst[j]: four fp32 values, or (bf, uniform) four bf16
+        // values as they are stored, in dst[j].x / .y -- widened where they are used (wide4), so that no conversion, and
+        // with it no wait, stands between the loads.
+        auto load_rows = [&](auto& dst, const float* base, int ld, bool bf) {
+            typedef typename std::remove_reference<decltype(dst[0])>::type elem_t;
+            constexpr bool RAW16 = std::is_same<elem_t, uint2>::value;
+            const int sh = (RAW16 || bf) ? 1 : 2;
+            // uniform; a 128-row group wholly past the matrix (second half of a 256-row workgroup) reads the last row
+            const char* b = reinterpret_cast<const char*>(base) + (((size_t)min(m0, p.M - 1) * ld + n0) << sh);
+            unsigned at[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int lr = (tid >> 5) + 8 * j;
-                rowc[j] = min(m0 + (lr >> 5) * 64 + rb * 32 + (lr & 31), p.M - 1);
-            }
-            if (USE_Y) {
+            for (int j = 0; j < 8; ++j) at[j] = (unsigned)(max(min(lrow(j), mlast), 0) * ld + cl) << sh;
+            if constexpr (RAW16) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) yq[j] = ld4x(p.bn_y, (size_t)rowc[j] * p.ldc + colc, p.r_bf16);
-            }
-            if (USE_R && p.R) {
+                for (int j = 0; j < 8; ++j) dst[j] = *reinterpret_cast<const uint2*>(b + at[j]);
+            } else {
+                if (bf) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) rq[j] = ld4x(p.R, (size_t)rowc[j] * p.ldr + colc, p.r_bf16);
-            }
-            if (USE_E) {
+                    for (int j = 0; j < 8; ++j) {
+                        const uint2 u = *reinterpret_cast<const uint2*>(b + at[j]);
+                        dst[j].x = __uint_as_float(u.x); dst[j].y = __uint_as_float(u.y);
+                    }
+                } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    eq1[j] = ld4(p.E1 + (size_t)rowc[j] * p.lde + colc);
-                    eq2[j] = ld4(p.E2 + (size_t)rowc[j] * p.lde + colc);
+                    for (int j = 0; j < 8; ++j) dst[j] = *reinterpret_cast<const float4*>(b + at[j]);
                 }
             }
+        };
+        auto wide2 = [](unsigned a, unsigned b) {
+            return make_float4(__uint_as_float(a << 16), __uint_as_float(a & 0xFFFF0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xFFFF0000u));
+        };
+        auto wide4 = [&](const aux_t v, bool bf) -> float4 {
+            if constexpr (AUX16) return wide2(v.x, v.y);
+            else return bf ? wide2(__float_as_uint(v.x), __float_as_uint(v.y)) : v;
+        };
+        const bool rbf = p.r_bf16 != 0;
+        if constexpr (USE_Y) load_rows(yq, p.bn_y, p.ldc, rbf);
+        if constexpr (USE_R) { if (p.R) load_rows(rq, p.R, p.ldr, rbf); }
+        if constexpr (USE_E) {
+            load_rows(eq1, p.E1, p.lde, false);
+            load_rows(eq2, p.E2, p.lde, false);
         }
-        // one output row (local row lr, global row `row`) of this thread's four columns
-        auto emit = [&](int j, int lr, int row) {
-            float4 v = ld4(lds + lr * EPL + c4);
-            const size_t o = (size_t)row * p.ldc + col;
-            if (USE_R && p.R) { const float4 q = rq[j]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        // one output row (slot j, row lr of the tile) of this thread's four columns
+        auto emit = [&](int j, int lr) {
+            float4 v = ld4(lds + (tr + 8 * j) * EPL + c4);
+            // address of the thread's four elements in an output with pitch ldc and element size 1 << sh
+            auto out_at = [&](float* base, int sh) -> char* {
+                return reinterpret_cast<char*>(base) + (((size_t)m0 * p.ldc + n0) << sh) + ((unsigned)(lr * p.ldc + c4) << sh);
+            };
+            char* o = out_at(Cz, shc);
+            if (USE_R && p.R) { const float4 q = wide4(rq[j], rbf); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
             if (EPI == EPI_PLAIN || EPI == EPI_BIAS) {
-                st4x(Cz, o, v, p.c_bf16);
+                st4b(o, v, p.c_bf16);
             } else if (EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE) {
-                st4x(Cz, o, v, p.c_bf16);
+                st4b(o, v, p.c_bf16);
                 vmax = amax4(vmax, v);
             } else if (EPI == EPI_GSTATS) {
-                st4x(Cz, o, v, p.c_bf16);
-                const float4 y = yq[j];
+                st4b(o, v, p.c_bf16);
+                const float4 y = wide4(yq[j], rbf);
                 bsb[0] += v.x; bsb[1] += v.y; bsb[2] += v.z; bsb[3] += v.w;
                 bk0[0] = fmaf(v.x, (y.x - bmu[0]) * bis[0], bk0[0]); bk0[1] = fmaf(v.y, (y.y - bmu[1]) * bis[1], bk0[1]);
                 bk0[2] = fmaf(v.z, (y.z - bmu[2]) * bis[2], bk0[2]); bk0[3] = fmaf(v.w, (y.w - bmu[3]) * bis[3], bk0[3]);
             } else if (EPI == EPI_BNBWD) {
-                const float4 y = yq[j];
+                const float4 y = wide4(yq[j], rbf);
                 float4 d;
                 d.x = y.x > 0.f ? bk0[0] * v.x - bk1[0] - bk2[0] * ((y.x - bmu[0]) * bis[0]) : 0.f;
                 d.y = y.y > 0.f ? bk0[1] * v.y - bk1[1] - bk2[1] * ((y.y - bmu[1]) * bis[1]) : 0.f;
                 d.z = y.z > 0.f ? bk0[2] * v.z - bk1[2] - bk2[2] * ((y.z - bmu[2]) * bis[2]) : 0.f;
                 d.w = y.w > 0.f ? bk0[3] * v.w - bk1[3] - bk2[3] * ((y.w - bmu[3]) * bis[3]) : 0.f;
-                st4x(Cz, o, d, p.c_bf16);
+                st4b(o, d, p.c_bf16);
                 vmax = amax4(vmax, d);
                 bsb[0] += d.x; bsb[1] += d.y; bsb[2] += d.z; bsb[3] += d.w;
             } else if (EPI == EPI_MUL) {
                 const float4 a = eq1[j], b = eq2[j];
-                st4(Cz + o, make_float4(v.x * a.x * b.x, v.y * a.y * b.y, v.z * a.z * b.z, v.w * a.w * b.w));
+                st4b(out_at(Cz, 2), make_float4(v.x * a.x * b.x, v.y * a.y * b.y, v.z * a.z * b.z, v.w * a.w * b.w), 0);
             } else if (EPI == EPI_HEAD) {
                 const float raw[4] = {v.x, v.y, v.z, v.w};
                 float val[4], df[4];
@@ -408,9 +341,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
                         df[e] = (raw[e] > 0.f && rl >= p.lo && rl <= p.hi) ? 1.f : 0.f;
                     }
                 }
-                st4(Cz + o, make_float4(val[0], val[1], val[2], val[3]));
-                if (p.C2) st4(p.C2 + o, make_float4(df[0], df[1], df[2], df[3]));
-                if (p.C3) st4(p.C3 + o, make_float4(val[0] * val[0], val[1] * val[1], val[2] * val[2], val[3] * val[3]));
+                st4b(out_at(Cz, 2), make_float4(val[0], val[1], val[2], val[3]), 0);
+                if (p.C2) st4b(out_at(p.C2, 2), make_float4(df[0], df[1], df[2], df[3]), 0);
+                if (p.C3) st4b(out_at(p.C3, 2), make_float4(val[0] * val[0], val[1] * val[1], val[2] * val[2], val[3] * val[3]), 0);
             }
         };
         if (p.c_bf16 && col >= p.N && col < p.ldc) {     // pad columns of a bf16 row: zeros (consumers copy whole 64-byte row pieces)
@@ -422,20 +355,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             }
         }
         if (col < p.N) {                               // N % 4 == 0 on this path: a 4-column group is in or out as a whole
-            if (m0 + BM <= p.M) {                      // interior row tile (uniform): no per-row checks
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int lr = (tid >> 5) + 8 * j;
-                    emit(j, lr, m0 + (lr >> 5) * 64 + rb * 32 + (lr & 31));
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int lr = (tid >> 5) + 8 * j;
-                    const int row = m0 + (lr >> 5) * 64 + rb * 32 + (lr & 31);
-                    if (row < p.M) emit(j, lr, row);
-                }
-            }
+            for (int j = 0; j < 8; ++j)
+                if (lrow(j) <= mlast) emit(j, lrow(j));
         }
         __syncthreads();
     }
@@ -510,10 +432,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
 }
 
 // `lds`: at least 36 KiB of LDS that no wave still reads as a tile
-template <int EPI>
+template <int EPI, bool AUX16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2][2], float* lds, int m0, int n0, int tile_m, int zz) {
-    if (p.c_vec) gemm_epilogue_staged<EPI>(p, acc, lds, m0, n0, tile_m, zz);
-    else         gemm_epilogue_direct<EPI>(p, acc, lds, m0, n0, tile_m, zz);
+    gemm_epilogue_staged<EPI, AUX16>(p, acc, lds, m0, n0, tile_m, zz);
 }
 
 }  // namespace btvae_gemm
