@@ -150,19 +150,30 @@ __device__ __forceinline__ void st4x(float* base, size_t i, const float4 v, int 
     const unsigned a = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, b2)), b = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, b2));
     *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + i) = make_uint2(a, b);
 }
-// the same at a byte address: a uniform row base plus a 32-bit lane offset stays `scalar base + one offset register`
+// the same at a byte address: a uniform row base plus a 32-bit lane offset stays `scalar base + one offset register`.
+// The accesses are spelled with native vector types: one 16-byte (8-byte) instruction each, where a float4 assigned
+// through a pointer made from bytes is stored member by member.
+typedef float nat_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned nat_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 ld4b(const char* a, int bf) {
-    if (!bf) return *reinterpret_cast<const float4*>(a);
-    const uint2 u = *reinterpret_cast<const uint2*>(a);
+    if (!bf) {
+        const nat_f4 v = *reinterpret_cast<const nat_f4*>(a);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    const nat_u2 u = *reinterpret_cast<const nat_u2*>(a);
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
 }
 __device__ __forceinline__ void st4b(char* a, const float4 v, int bf) {
-    if (!bf) { *reinterpret_cast<float4*>(a) = v; return; }
+    if (!bf) {
+        const nat_f4 q = {v.x, v.y, v.z, v.w};
+        *reinterpret_cast<nat_f4*>(a) = q;
+        return;
+    }
     typedef __bf16 b2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 lo = {v.x, v.y}, hi = {v.z, v.w};
-    const unsigned x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, b2)), y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, b2));
-    *reinterpret_cast<uint2*>(a) = make_uint2(x, y);
+    const nat_u2 q = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo, b2)), __builtin_bit_cast(unsigned, __builtin_convertvector(hi, b2))};
+    *reinterpret_cast<nat_u2*>(a) = q;
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) {

@@ -111,7 +111,10 @@ __device__ __forceinline__ float4 ld4(const float* q) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* q, const float4 v) { *reinterpret_cast<float4*>(q) = v; }
 // AUX16: the matrices read here (add-in, BatchNorm input) are known to hold bf16 (p.r_bf16 set): they wait for their use
 // in half the registers.
-template <int EPI, bool AUX16 = false>
+// ROWS: how many of a thread's eight rows are read from the LDS image before their stores are issued on a row tile inside
+// the matrix: 8; fewer in the kernels whose 128 accumulator registers leave no room for eight rows in flight; 1 = every
+// tile takes the row-by-row path of the edge tiles (no second copy of the store code either).
+template <int EPI, bool AUX16 = false, int ROWS = 8>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[2][2], float* lds, int m0, int n0, int tile_m, int zz) {
     const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
@@ -262,17 +265,23 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             for (int j = 0; j < 8; ++j) at[j] = (unsigned)(max(min(lrow(j), mlast), 0) * ld + cl) << sh;
             if constexpr (RAW16) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) dst[j] = *reinterpret_cast<const uint2*>(b + at[j]);
+                for (int j = 0; j < 8; ++j) {
+                    const nat_u2 u = *reinterpret_cast<const nat_u2*>(b + at[j]);
+                    dst[j] = make_uint2(u.x, u.y);
+                }
             } else {
                 if (bf) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const uint2 u = *reinterpret_cast<const uint2*>(b + at[j]);
-                        dst[j].x = __uint_as_float(u.x); dst[j].y = __uint_as_float(u.y);
+                        const nat_u2 u = *reinterpret_cast<const nat_u2*>(b + at[j]);
+                        dst[j] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f);
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) dst[j] = *reinterpret_cast<const float4*>(b + at[j]);
+                    for (int j = 0; j < 8; ++j) {
+                        const nat_f4 v = *reinterpret_cast<const nat_f4*>(b + at[j]);
+                        dst[j] = make_float4(v.x, v.y, v.z, v.w);
+                    }
                 }
             }
         };
@@ -291,8 +300,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             load_rows(eq2, p.E2, p.lde, false);
         }
         // one output row (slot j, row lr of the tile) of this thread's four columns
-        auto emit = [&](int j, int lr) {
-            float4 v = ld4(lds + (tr + 8 * j) * EPL + c4);
+        auto emit = [&](int j, int lr, float4 v) {
             // address of the thread's four elements in an output with pitch ldc and element size 1 << sh
             auto out_at = [&](float* base, int sh) -> char* {
                 return reinterpret_cast<char*>(base) + (((size_t)m0 * p.ldc + n0) << sh) + ((unsigned)(lr * p.ldc + c4) << sh);
@@ -355,9 +363,22 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             }
         }
         if (col < p.N) {                               // N % 4 == 0 on this path: a 4-column group is in or out as a whole
+            auto image_row = [&](int j) { return ld4(lds + (tr + 8 * j) * EPL + c4); };
+            if (ROWS > 1 && mlast >= BM - 1) {         // row tile inside the matrix (uniform): ROWS LDS reads, then their stores;
+#pragma unroll                                         // behind per-row tests every row waits for its own read
+                for (int j0 = 0; j0 < 8; j0 += ROWS) {
+                    float4 v[ROWS];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (lrow(j) <= mlast) emit(j, lrow(j));
+                    for (int j = 0; j < ROWS; ++j) v[j] = image_row(j0 + j);
+#pragma unroll
+                    for (int j = 0; j < ROWS; ++j) emit(j0 + j, lrow(j0 + j), v[j]);
+                    if (ROWS < 8) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (lrow(j) <= mlast) emit(j, lrow(j), image_row(j));
+            }
         }
         __syncthreads();
     }
@@ -432,9 +453,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
 }
 
 // `lds`: at least 36 KiB of LDS that no wave still reads as a tile
-template <int EPI, bool AUX16 = false>
+template <int EPI, bool AUX16 = false, int ROWS = 8>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[2][2], float* lds, int m0, int n0, int tile_m, int zz) {
-    gemm_epilogue_staged<EPI, AUX16>(p, acc, lds, m0, n0, tile_m, zz);
+    gemm_epilogue_staged<EPI, AUX16, ROWS>(p, acc, lds, m0, n0, tile_m, zz);
 }
 
 }  // namespace btvae_gemm

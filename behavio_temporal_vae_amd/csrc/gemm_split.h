@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && BL == L
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[h][i][j][r] = (acc[h][i][j][r] * ia) * ib;
         }
-        gemm_epilogue<EPI>(p, acc[h], reinterpret_cast<float*>(smem_raw), m0, n0 + h * BN, tile_m, zz);
+        gemm_epilogue<EPI, false, NB == 2 ? 1 : 8>(p, acc[h], reinterpret_cast<float*>(smem_raw), m0, n0 + h * BN, tile_m, zz);
     }
 }
 
