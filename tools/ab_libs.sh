@@ -1,5 +1,7 @@
 #!/bin/bash
-# A/B of two builds of the library on one box: headline step + scoring leg, alternating
+# A/B of two builds of the library on one box (box-to-box spread is larger than most kernel changes): headline step and
+# scoring leg, alternating.  tools/libbtvae_old.so = the build to compare with (e.g. `git archive <rev> behavio_temporal_vae_amd/csrc`
+# built elsewhere); the in-tree build is "new".  Run from the repository root on the GPU box.
 for rep in 1 2; do
   for lib in old new; do
     if [ $lib = old ]; then export BTVAE_HIP_LIB=$PWD/tools/libbtvae_old.so; else unset BTVAE_HIP_LIB; fi

@@ -1,6 +1,10 @@
+"""Which products trip the guard of the two-piece mode on the config0 training step (site = weight tensor + role):
+
+    python tools/guard_sites.py [batch=4096] [iterations=30]
+"""
 import sys, os, contextlib, io
 import numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 from behavio_temporal_vae_amd.vae_models import CVAE
 from behavio_temporal_vae_amd import engine as E

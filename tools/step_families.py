@@ -1,6 +1,11 @@
+"""Per-family kernel time of the config0 training step (HIP events around every launch of 3 steps) and the dominant
+launch of each product family:
+
+    [DBG_B=4096] [BTVAE_STEP_GRAPH=0] python tools/step_families.py [fp32_split2 | fp32_split | fp32 | bf16]
+"""
 import sys, os, contextlib, io
 import numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
 from behavio_temporal_vae_amd.vae_models import CVAE
 from behavio_temporal_vae_amd import engine as E, _native as nv
@@ -13,7 +18,7 @@ model.set_gemm_precision(sys.argv[1] if len(sys.argv) > 1 else "bf16")
 model.train_kwargs = dict(bench.CONFIG0_TRAIN)
 opt = model.get_optimizer(lr=1e-3, weight_decay=1e-5)
 rng = np.random.default_rng(0)
-B = 4096
+B = int(os.environ.get("DBG_B", "4096"))
 x, c = bench.synth_batch(rng, B)
 x, c = torch.from_numpy(x).to(dev), torch.from_numpy(c).to(dev)
 for it in range(5):
