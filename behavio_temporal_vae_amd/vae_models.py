@@ -10,6 +10,7 @@ flat-buffer operations.  There is no CPU compute path: tensors must be on an MI3
 from __future__ import annotations
 
 import datetime
+import gc
 import json
 import os
 import weakref
@@ -734,39 +735,52 @@ class VAE(torch.nn.Module):
 
         self.train()
         itx = 0
-        for epx in range(1, epochs + 1):
-            if pbar_e is not None:
-                pbar_e.update(1); pbar_i.reset()
-            for batch in trainloader:
-                itx += 1
-                if pbar_i is not None:
-                    pbar_i.update(1)
-                loss = self.train_core(self.move_to_device(batch, device=device), optim)
-                if valloader is not None and itx % validation_freq == 0:
-                    val = self.validate(valloader, num_mc_samples=validation_mc_samples, device=device)
-                    say(f"Validation -- ELBO={val['elbo']:.4e} / RLL={val['rll']:.4e} / KL={val['kl']:.4e}")
-                    if scheduler is not None:
-                        before = scheduler.get_last_lr()[0]
-                        scheduler.step(val["elbo"])
-                        after = scheduler.get_last_lr()[0]
-                        if after != before:
-                            say(f"Learning Rate Changed: {before} -> {after}")
-                    if stopper is not None:
-                        stopper(val["elbo"], pbar=pbar_i)
-                    if tensorboard:
-                        for k, tag in (("elbo", "Loss/ELBO"), ("rll", "Loss/RLL"), ("kl", "Loss/KL")):
-                            writer.add_scalars(tag, {"val": val[k]}, itx)
-                    self.train()
-                if itx % verbose_freq == 0:
-                    self.train_verbose(itx, loss, pbar=pbar_i)
-                    if tensorboard:
-                        for k, tag in (("elbo", "Loss/ELBO"), ("rll", "Loss/RLL"), ("kl", "Loss/KL")):
-                            writer.add_scalars(tag, {"train": loss[k]}, itx)
-            if save_epoch_freq is not None and epx % save_epoch_freq == 0:
-                self.save(device=device)
-                (pbar_e.write if pbar_e is not None else print)(f"Model Saved at Epoch {epx} to {self.log_dir}")
-            if stopper is not None and stopper.early_stop:
-                break
+        # The interpreter's full collections walk every object the imports left behind (tens of milliseconds in which nothing
+        # is launched: several steps' worth); once the loop's own objects exist they are moved out of the collector's
+        # reach for the duration of the loop.  BTVAE_GC_FREEZE=0 leaves the collector alone.
+        freeze_at = 8 if os.environ.get("BTVAE_GC_FREEZE", "1") != "0" else -1
+        frozen = False
+        try:
+            for epx in range(1, epochs + 1):
+                if pbar_e is not None:
+                    pbar_e.update(1); pbar_i.reset()
+                for batch in trainloader:
+                    itx += 1
+                    if itx == freeze_at:
+                        gc.collect()
+                        gc.freeze()
+                        frozen = True
+                    if pbar_i is not None:
+                        pbar_i.update(1)
+                    loss = self.train_core(self.move_to_device(batch, device=device), optim)
+                    if valloader is not None and itx % validation_freq == 0:
+                        val = self.validate(valloader, num_mc_samples=validation_mc_samples, device=device)
+                        say(f"Validation -- ELBO={val['elbo']:.4e} / RLL={val['rll']:.4e} / KL={val['kl']:.4e}")
+                        if scheduler is not None:
+                            before = scheduler.get_last_lr()[0]
+                            scheduler.step(val["elbo"])
+                            after = scheduler.get_last_lr()[0]
+                            if after != before:
+                                say(f"Learning Rate Changed: {before} -> {after}")
+                        if stopper is not None:
+                            stopper(val["elbo"], pbar=pbar_i)
+                        if tensorboard:
+                            for k, tag in (("elbo", "Loss/ELBO"), ("rll", "Loss/RLL"), ("kl", "Loss/KL")):
+                                writer.add_scalars(tag, {"val": val[k]}, itx)
+                        self.train()
+                    if itx % verbose_freq == 0:
+                        self.train_verbose(itx, loss, pbar=pbar_i)
+                        if tensorboard:
+                            for k, tag in (("elbo", "Loss/ELBO"), ("rll", "Loss/RLL"), ("kl", "Loss/KL")):
+                                writer.add_scalars(tag, {"train": loss[k]}, itx)
+                if save_epoch_freq is not None and epx % save_epoch_freq == 0:
+                    self.save(device=device)
+                    (pbar_e.write if pbar_e is not None else print)(f"Model Saved at Epoch {epx} to {self.log_dir}")
+                if stopper is not None and stopper.early_stop:
+                    break
+        finally:
+            if frozen:
+                gc.unfreeze()
         self.to("cpu")
         self._prior_to("cpu")
         self.eval()
