@@ -249,8 +249,8 @@ class _MaxSlots:
         if self.chunk is None or self.used == self.CHUNK or self.chunk.device != dev:
             if self.chunk is not None:
                 self.held.append(self.chunk)
-            self.chunk, self.used = torch.zeros(self.CHUNK, device=dev), 0      # a fill kernel (a memset node in a captured
-                                                                                 # graph does not hold its place: btvae_slots_zero)
+            self.chunk, self.used = torch.zeros(self.CHUNK, device=dev), 0      # a fill kernel (a captured memset node has no
+                                                                                 # effect on memory of the graph's own allocation node)
         self.used += 2
         return self.chunk[self.used - 2:self.used]
 

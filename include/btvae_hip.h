@@ -63,7 +63,7 @@ int btvae_weight_planes_multi(const float* const* W, const int* N, const int* K,
  * the tensor); both start at zero.  Every amax / amax_out pointer below points at such a pair.
  * btvae_absmax folds max|x| over n floats into the slot *out, which must hold zeros or a maximum to extend;
  * btvae_slots_zero clears n neighbouring slots with a kernel launch (use it rather than hipMemsetAsync on a stream that may
- * be under capture: a memset node was seen not to keep its place among a graph's kernel nodes).
+ * be under capture: on memory that belongs to the graph's own allocation node a captured memset node has no effect, ROCm 7.2).
  * btvae_gemm_operand_maxima names the device scalars holding the maxima of the A operand (activations or gradients)
  * and the B operand (weight, or activations for a weight gradient) of the NEXT product launched from the calling
  * thread; that launch consumes them.  Each must be final on the product's stream and cover every element the product
