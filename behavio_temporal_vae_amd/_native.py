@@ -39,6 +39,10 @@ _SIGS = {
     "btvae_slots_zero": [P, I, P],
     "btvae_guard_check": [P, P, I, P],
     "btvae_weight_image_bf16": [P, I, I, I, I, P, P],
+    "btvae_pairs_encode": [P, I, P, I, P, I, I, P],
+    "btvae_pairs_decode": [P, I, P, P, I, I, I, P],
+    "btvae_weight_image_pq": [P, I, I, I, I, P, P, P],
+    "btvae_linear_relu_affine_fwd_pairs": [P, I, P, P, P, P, P, P, P, P, I, P, I, I, I, P],
     "btvae_weight_image_bf16_multi": [P, P, P, P, P, I, P],
     "btvae_linear_head_fwd": [P, I, P, P, I, F, F, P, P, P, I, I, I, P],
     "btvae_linear_head_fwd_ws": [P, I, P, P, I, F, F, P, P, P, P, LL, I, I, I, P],
@@ -100,6 +104,7 @@ _RET = {
     "btvae_bn_relu_bwd_scratch": (c_longlong, [I, I]),
     "btvae_weight_planes_elems": (c_longlong, [I, I]),
     "btvae_weight_image_bf16_bytes": (c_longlong, [I, I, I]),
+    "btvae_weight_image_pq_bytes": (c_longlong, [I, I, I]),
     "btvae_next_bf16": (c_int, [I]),
     "btvae_colsum_noalloc_max_floats": (c_longlong, []),
     "btvae_prof_enabled": (c_int, []),

@@ -599,6 +599,7 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
               (!a.R || (a.ldr % 4 == 0 && aligned16(a.R))) && (!a.C2 || aligned16(a.C2)) && (!a.C3 || aligned16(a.C3)) &&
               (EPI != EPI_MUL || (a.lde % 4 == 0 && aligned16(a.E1) && aligned16(a.E2)));
     if (splits < 1) splits = 1;
+    BTVAE_REQUIRE(!a.c_sc || (EPI == EPI_RELU_AFFINE && a.c_vec && !a.R), "%s: pair-format output needs a 16-byte addressable output and no add-in", what);
     const int prec = g_precision.load(std::memory_order_relaxed);
     // matrices stored as bf16 (btvae_next_bf16): bf16 mode only, staged epilogue only, extents in whole 16-byte pieces
     const int bmask = btvae::take_bf16_mask();
@@ -607,6 +608,7 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     if (bmask) {
         BTVAE_REQUIRE(reduced_ok && prec == 1, "%s: bf16-stored matrices are a feature of the bf16 mode's Linear products", what);
         BTVAE_REQUIRE(a.c_vec, "%s: bf16-stored matrices need 16-byte addressable outputs and add-ins (N %% 4 == 0, pitches %% 4 == 0)", what);
+        BTVAE_REQUIRE(!a.c_sc, "%s: pair-format output and bf16-stored matrices do not mix", what);
         if (a.a_bf16) a.a_vec = (a.lda % 8 == 0) && aligned16(a.A) && ((AL == LAY_K ? a.K : a.M) % 8 == 0);
         if (a.b_bf16) a.b_vec = (a.ldb % 8 == 0) && aligned16(a.B) && ((BL == LAY_K ? a.K : a.N) % 8 == 0);
         BTVAE_REQUIRE(a.a_vec && a.b_vec, "%s: a bf16-stored operand needs a 16-byte aligned base, a pitch and an extent that are multiples of 8", what);
@@ -672,7 +674,6 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     return btvae::check_launch(what);
 }
 
-#ifdef BTVAE_EXPERIMENTS
 // ---- pair format (pairs.h) -------------------------------------------------------------------------------------------
 // One workgroup per 128 x 128 block: thread t holds columns 4 (t & 31) .. + 3 of rows (t >> 5) + 8 j.  The block's maximum
 // decides its scale before anything is written, so X and P may be the same buffer (a block's bytes are the same in both
@@ -719,29 +720,6 @@ __global__ __launch_bounds__(256) void pairs_decode_kernel(const unsigned short*
     }
 }
 
-// products whose A operand is in the pair format: B pre-split into fp16 planes (a.Bp) with its maximum in a.amax_b
-template <int BL, int EPI>
-int launch_pairs(GemmArgs& a, int variant, hipStream_t s, const char* what) {
-    a.amax_a = nullptr;
-    a.amax_out = btvae::take_output_maximum();
-    if (EPI != EPI_RELU_STATS && EPI != EPI_RELU_AFFINE && EPI != EPI_BNBWD) a.amax_out = nullptr;
-    BTVAE_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "%s: empty problem M=%d N=%d K=%d", what, a.M, a.N, a.K);
-    BTVAE_REQUIRE(a.A && a.a_sc && a.Bp && a.amax_b && a.C, "%s: null operand", what);
-    BTVAE_REQUIRE(a.K % 8 == 0 && a.lda % 16 == 0 && a.lda >= a.K && aligned16(a.A), "%s: pair-format operand needs K %% 8 == 0, a 16-byte aligned base and a pitch that is a multiple of 16 (K %d, pitch %d)", what, a.K, a.lda);
-    BTVAE_REQUIRE(a.ldc >= a.N, "%s: ldc %d < N %d", what, a.ldc, a.N);
-    a.tiles_m = (a.M + BM - 1) / BM;
-    a.a_scn = (a.K + 127) / 128;
-    a.a_vec = a.b_vec = 1;
-    a.c_vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && aligned16(a.C) && (!a.R || (a.ldr % 4 == 0 && aligned16(a.R)));
-    const bool wide = variant == 1 && a.N > BN;
-    a.tiles_n = (a.N + (wide ? 2 * BN : BN) - 1) / (wide ? 2 * BN : BN);
-    a.kchunk = (a.K + SBK - 1) / SBK * SBK;
-    dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, 1);
-    if (wide) hipLaunchKernelGGL((gemm_split_mfma<LAY_K, BL, EPI, true, 2, 2, 1>), grid, dim3(256), 0, s, a);
-    else      hipLaunchKernelGGL((gemm_split_mfma<LAY_K, BL, EPI, true, 2, 1, 1>), grid, dim3(256), 0, s, a);
-    return btvae::check_launch(what);
-}
-
 // B[n][k] (n < Nn output columns, k < Kk reduction steps) = W[n][k], or W[k][n] when `transpose`, as the stage images
 // gemm_pq256 copies into LDS: blocks [ceil(Nn/256)][ceil(Kk/16)] of 256 rows x 64 bytes (q_off), two fp16 pieces of the
 // value times the power of two *amax selects, zero padded.  One thread per row and 8-k half.
@@ -781,12 +759,38 @@ int launch_pq256(GemmArgs& a, int groups, hipStream_t s, const char* what) {
     a.bp_tiles = (a.K + 15) / 16;
     a.a_vec = a.b_vec = 1;
     a.c_vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && aligned16(a.C) && (!a.R || (a.ldr % 4 == 0 && aligned16(a.R)));
+    BTVAE_REQUIRE(!a.c_sc || (EPI == EPI_RELU_AFFINE && a.c_vec), "%s: pair-format output needs a 16-byte addressable output", what);
+    BTVAE_REQUIRE(EPI != EPI_RELU_AFFINE || !a.R, "%s: no add-in on a pair-format operand", what);
     a.kchunk = a.bp_tiles * 16;
 #ifdef BTVAE_PQ_ABLATE
     { const char* e = getenv("BTVAE_PQ_ABLATE"); a.lde = e ? atoi(e) : 0; }
 #endif
     if (groups == 2) hipLaunchKernelGGL((gemm_pq256<EPI, 2>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(512), 0, s, a);
     else             hipLaunchKernelGGL((gemm_pq256<EPI, 1>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), 0, s, a);
+    return btvae::check_launch(what);
+}
+
+#ifdef BTVAE_EXPERIMENTS
+// products whose A operand is in the pair format: B pre-split into fp16 planes (a.Bp) with its maximum in a.amax_b
+template <int BL, int EPI>
+int launch_pairs(GemmArgs& a, int variant, hipStream_t s, const char* what) {
+    a.amax_a = nullptr;
+    a.amax_out = btvae::take_output_maximum();
+    if (EPI != EPI_RELU_STATS && EPI != EPI_RELU_AFFINE && EPI != EPI_BNBWD) a.amax_out = nullptr;
+    BTVAE_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "%s: empty problem M=%d N=%d K=%d", what, a.M, a.N, a.K);
+    BTVAE_REQUIRE(a.A && a.a_sc && a.Bp && a.amax_b && a.C, "%s: null operand", what);
+    BTVAE_REQUIRE(a.K % 8 == 0 && a.lda % 16 == 0 && a.lda >= a.K && aligned16(a.A), "%s: pair-format operand needs K %% 8 == 0, a 16-byte aligned base and a pitch that is a multiple of 16 (K %d, pitch %d)", what, a.K, a.lda);
+    BTVAE_REQUIRE(a.ldc >= a.N, "%s: ldc %d < N %d", what, a.ldc, a.N);
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.a_scn = (a.K + 127) / 128;
+    a.a_vec = a.b_vec = 1;
+    a.c_vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && aligned16(a.C) && (!a.R || (a.ldr % 4 == 0 && aligned16(a.R)));
+    const bool wide = variant == 1 && a.N > BN;
+    a.tiles_n = (a.N + (wide ? 2 * BN : BN) - 1) / (wide ? 2 * BN : BN);
+    a.kchunk = (a.K + SBK - 1) / SBK * SBK;
+    dim3 grid((unsigned)(a.tiles_m * a.tiles_n), 1, 1);
+    if (wide) hipLaunchKernelGGL((gemm_split_mfma<LAY_K, BL, EPI, true, 2, 2, 1>), grid, dim3(256), 0, s, a);
+    else      hipLaunchKernelGGL((gemm_split_mfma<LAY_K, BL, EPI, true, 2, 1, 1>), grid, dim3(256), 0, s, a);
     return btvae::check_launch(what);
 }
 
@@ -1025,7 +1029,7 @@ BTVAE_API int btvae_weight_image_bf16_multi(const float* const* W, const int* N,
     return check_launch("weight_image_bf16_multi");
 }
 
-#ifdef BTVAE_EXPERIMENTS
+// ---- pair format (pairs.h): the eval-mode chains of the two-piece mode keep their hidden activations in it ------------
 // fp32 X[M][N] (row pitch ldx) -> pair format P (the bytes of an fp32 matrix of pitch ldp, ldp % 16 == 0, N % 8 == 0) and
 // its block scales sc[ceil(M/128)][ceil(N/128)]; P may be X itself when ldp == ldx.
 BTVAE_API int btvae_pairs_encode(const float* X, int ldx, void* P, int ldp, float* sc, int M, int N, void* stream) {
@@ -1047,20 +1051,6 @@ BTVAE_API int btvae_pairs_decode(const void* P, int ldp, const float* sc, float*
     return check_launch("pairs_decode");
 }
 
-// btvae_linear_relu_stats_fwd_pw with X in the pair format (Xp, pitch ldx floats, block scales xsc); Wplanes are fp16
-// planes (btvae_weight_planes_f16) and wmax the maximum they were made with.  variant 1: 128 x 256 block tile.
-BTVAE_API int btvae_linear_relu_stats_fwd_pq(const void* Xp, int ldx, const float* xsc, const void* Wplanes, const float* wmax, const float* b,
-                                             float* Y, float* stat_partials, int M, int K, int N, int variant, void* stream) {
-    const RowPitches rp = take_row_pitches();
-    int ldy;
-    BTVAE_REQUIRE(pitch_of(rp.n, N, ldy), "linear_relu_stats_fwd_pq: row pitch %d below N = %d", rp.n, N);
-    BTVAE_REQUIRE(b && stat_partials, "linear_relu_stats_fwd_pq: null bias/stats");
-    GemmArgs a{}; a.A = (const float*)Xp; a.lda = ldx; a.a_sc = xsc; a.C = Y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
-    a.bias = b; a.stats = stat_partials; set_planes(a, Wplanes, N, K, false); a.amax_b = wmax;
-    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    return launch_pairs<LAY_K, EPI_RELU_STATS>(a, variant, (hipStream_t)stream, "linear_relu_stats_fwd_pq");
-}
-
 // Stage images of a weight matrix W[R][C] for the 256 x 256 pair-format products: transpose = 0 for the forward products
 // (output columns = rows of W), 1 for the dX products (output columns = columns of W).  *amax = max |W| (device scalar).
 BTVAE_API long long btvae_weight_image_pq_bytes(int R, int C, int transpose) {
@@ -1076,6 +1066,22 @@ BTVAE_API int btvae_weight_image_pq(const float* W, int ldw, int R, int C, int t
                        W, ldw, Nn, Kk, transpose, (char*)image, amax);
     return check_launch("weight_image_pq");
 }
+
+#ifdef BTVAE_EXPERIMENTS
+// btvae_linear_relu_stats_fwd_pw with X in the pair format (Xp, pitch ldx floats, block scales xsc); Wplanes are fp16
+// planes (btvae_weight_planes_f16) and wmax the maximum they were made with.  variant 1: 128 x 256 block tile.
+BTVAE_API int btvae_linear_relu_stats_fwd_pq(const void* Xp, int ldx, const float* xsc, const void* Wplanes, const float* wmax, const float* b,
+                                             float* Y, float* stat_partials, int M, int K, int N, int variant, void* stream) {
+    const RowPitches rp = take_row_pitches();
+    int ldy;
+    BTVAE_REQUIRE(pitch_of(rp.n, N, ldy), "linear_relu_stats_fwd_pq: row pitch %d below N = %d", rp.n, N);
+    BTVAE_REQUIRE(b && stat_partials, "linear_relu_stats_fwd_pq: null bias/stats");
+    GemmArgs a{}; a.A = (const float*)Xp; a.lda = ldx; a.a_sc = xsc; a.C = Y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
+    a.bias = b; a.stats = stat_partials; set_planes(a, Wplanes, N, K, false); a.amax_b = wmax;
+    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    return launch_pairs<LAY_K, EPI_RELU_STATS>(a, variant, (hipStream_t)stream, "linear_relu_stats_fwd_pq");
+}
+
 // Y (bf16, pitch ldy elements) = relu(X (bf16, pitch ldx elements) W^T + b), W from its bf16 stage images
 BTVAE_API int btvae_linear_relu_stats_fwd_bh256(const void* X, int ldx, const void* Wimage, const float* b, void* Y, int ldy,
                                                 float* stat_partials, int M, int K, int N, int groups, void* stream) {
@@ -1114,6 +1120,34 @@ BTVAE_API int btvae_linear_relu_affine_fwd_pw_ld(const float* X, int ldx, const 
     a.bias = b; a.scale = scale; a.shift = shift; a.R = R; a.ldr = ldr; set_planes(a, Wplanes, N, K, false);
     ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     return launch<LAY_K, LAY_K, EPI_RELU_AFFINE>(a, 1, (hipStream_t)stream, "linear_relu_affine_fwd", true);
+}
+
+// The same unit with its activations in the pair format (eval-mode chains of the two-piece mode; no add-in).
+//   X: fp32 (x_sc null; W's fp16 planes in Wsplit, operand maxima through btvae_gemm_operand_maxima as for the call above)
+//      or pairs (x_sc = its block scales; Wsplit = btvae_weight_image_pq image made with the maximum *wmax);
+//   Out: fp32 (out_sc null) or pairs (out_sc[ceil(M/128)][ceil(N/128)] receives the block scales; ldo % 16 == 0, pad columns zeroed).
+// Pitches count floats in both formats (a pair-format row has the bytes of the fp32 row it replaces).
+BTVAE_API int btvae_linear_relu_affine_fwd_pairs(const void* X, int ldx, const float* x_sc, const float* W, const void* Wsplit, const float* wmax,
+                                                 const float* b, const float* scale, const float* shift, void* Out, int ldo, float* out_sc,
+                                                 int M, int K, int N, void* stream) {
+    BTVAE_REQUIRE(b, "linear_relu_affine_fwd_pairs: null bias");
+    BTVAE_REQUIRE(ldo >= N && (!out_sc || (ldo % 16 == 0 && N % 4 == 0 && aligned16(Out))),
+                  "linear_relu_affine_fwd_pairs: pair-format output needs N %% 4 == 0, a 16-byte aligned base and a pitch that is a multiple of 16 (N %d, pitch %d)", N, ldo);
+    GemmArgs a{}; a.C = (float*)Out; a.ldc = ldo; a.M = M; a.N = N; a.K = K;
+    a.bias = b; a.scale = scale; a.shift = shift; a.c_sc = out_sc; a.c_scn = (N + 127) / 128;
+    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    if (x_sc) {
+        BTVAE_REQUIRE(g_precision.load(std::memory_order_relaxed) == 3, "linear_relu_affine_fwd_pairs: pair-format operands belong to the two-piece mode");
+        BTVAE_REQUIRE(Wsplit && wmax, "linear_relu_affine_fwd_pairs: a pair-format operand needs the weight's stage images and its maximum");
+        a.A = (const float*)X; a.lda = ldx; a.a_sc = x_sc; a.Bp = (const unsigned short*)Wsplit; a.amax_b = wmax;
+        const int wide_tiles = ((M + 255) / 256) * ((N + QN - 1) / QN);
+        static const int forced = [] { const char* e = getenv("BTVAE_PQ256_GROUPS"); return e ? atoi(e) : 0; }();   // tuning: 1 / 2 rows of 128 per workgroup
+        const int groups = forced == 1 ? 1 : (wide_tiles >= 256 ? 2 : 1);
+        return launch_pq256<EPI_RELU_AFFINE>(a, groups, (hipStream_t)stream, "linear_relu_affine_fwd_pairs");
+    }
+    BTVAE_REQUIRE(W, "linear_relu_affine_fwd_pairs: null weight");
+    a.A = (const float*)X; a.lda = ldx; a.B = W; a.ldb = K; set_planes(a, Wsplit, N, K, false);
+    return launch<LAY_K, LAY_K, EPI_RELU_AFFINE>(a, 1, (hipStream_t)stream, "linear_relu_affine_fwd_pairs", true);
 }
 BTVAE_API int btvae_linear_relu_affine_fwd_pw(const float* X, int ldx, const float* W, const void* Wplanes, const float* b, const float* scale,
                                               const float* shift, const float* R, float* Out, int M, int K, int N, void* stream) {

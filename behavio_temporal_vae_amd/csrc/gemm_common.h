@@ -3,6 +3,7 @@
 // of a tile = row (r&3)+8(r>>2)+4*(lane>>5), column lane&31), so one epilogue serves both.
 #pragma once
 #include "common.h"
+#include "pairs.h"
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -45,6 +46,9 @@ struct GemmArgs {
     float* amax_out;            // null, or where max |stored C| is folded in (EPI_RELU_STATS, EPI_RELU_AFFINE, EPI_BNBWD)
     // A operand stored as fp16 pairs with one power-of-two scale per 128 x 128 block (pairs.h): a_sc[row tile][a_scn]
     const float* a_sc; int a_scn;
+    // EPI_RELU_AFFINE: non-null = the output is written in that format, one block per 128 x 128 tile, its scales to
+    // c_sc[row tile][c_scn] (ldc counts floats: a pair-format row has the bytes of the fp32 row it replaces); no add-in then
+    float* c_sc; int c_scn;
     // hidden activations / gradients stored as bf16 (the bf16 mode's storage format; leading dimensions then count bf16
     // elements): the output C, and the add-in R together with the BatchNorm input bn_y.  Staged epilogue only.
     int c_bf16, r_bf16;
@@ -114,7 +118,8 @@ __device__ __forceinline__ void st4(float* q, const float4 v) { *reinterpret_cas
 // ROWS: how many of a thread's eight rows are read from the LDS image before their stores are issued on a row tile inside
 // the matrix: 8; fewer in the kernels whose 128 accumulator registers leave no room for eight rows in flight; 1 = every
 // tile takes the row-by-row path of the edge tiles (no second copy of the store code either).
-template <int EPI, bool AUX16 = false, int ROWS = 8>
+// PQOUT: the kernel may be asked for pair-format output (p.c_sc; EPI_RELU_AFFINE only).  NOADD: it is never given an add-in.
+template <int EPI, bool AUX16 = false, int ROWS = 8, bool PQOUT = true, bool NOADD = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[2][2], float* lds, int m0, int n0, int tile_m, int zz) {
     const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
@@ -157,6 +162,26 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             bk0[e] = gi;
             bk1[e] = ok ? gi * p.bn_sums[c] * p.bn_inv_rows : 0.f;
             bk2[e] = ok ? gi * p.bn_sums[p.N + c] * p.bn_inv_rows : 0.f;
+        }
+    }
+
+    // Pair-format output (EPI_RELU_AFFINE, p.c_sc): the tile is one block of that format; its scale comes from the largest
+    // value the tile will store, found before anything is written
+    float pq_s = 1.f;
+    if constexpr (EPI == EPI_RELU_AFFINE && PQOUT) {
+        if (p.c_sc) {                                  // uniform
+            float m = 0.f;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(fmaxf(acc[rb][cb][r] + bias[cb], 0.f) * sc[cb] + sh[cb]));
+            m = wave_max(m);
+            if (lane == 0) red[wid] = m;
+            __syncthreads();
+            pq_s = btvae_pairs::pq_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+            if (tid == 0 && m0 < p.M) p.c_sc[(size_t)(m0 >> 7) * p.c_scn + (n0 >> 7)] = pq_s;
         }
     }
 
@@ -245,7 +270,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
         const int mlast = p.M - 1 - m0;                 // last valid row of the tile (>= 127 inside the matrix); uniform
         const int shc = p.c_bf16 ? 1 : 2;
         auto lrow = [&](int j) { return (j >> 2) * 64 + rb * 32 + 8 * (j & 3) + tr; };
-        constexpr bool USE_R = EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_RELU_AFFINE || EPI == EPI_GSTATS || EPI == EPI_BNBWD;
+        constexpr bool USE_R = !NOADD && (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_RELU_AFFINE || EPI == EPI_GSTATS || EPI == EPI_BNBWD);
         constexpr bool USE_Y = EPI == EPI_GSTATS || EPI == EPI_BNBWD;
         constexpr bool USE_E = EPI == EPI_MUL;
         typedef typename std::conditional<AUX16, uint2, float4>::type aux_t;
@@ -310,7 +335,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             if (EPI == EPI_PLAIN || EPI == EPI_BIAS) {
                 st4b(o, v, p.c_bf16);
             } else if (EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE) {
-                st4b(o, v, p.c_bf16);
+                if (EPI == EPI_RELU_AFFINE && PQOUT && p.c_sc) btvae_pairs::pq_store4(reinterpret_cast<unsigned short*>(out_at(Cz, 2) - ((size_t)col << 2)), col, v, pq_s);
+                else st4b(o, v, p.c_bf16);
                 vmax = amax4(vmax, v);
             } else if (EPI == EPI_GSTATS) {
                 st4b(o, v, p.c_bf16);
@@ -354,12 +380,16 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
                 if (p.C3) st4b(out_at(p.C3, 2), make_float4(val[0] * val[0], val[1] * val[1], val[2] * val[2], val[3] * val[3]), 0);
             }
         };
-        if (p.c_bf16 && col >= p.N && col < p.ldc) {     // pad columns of a bf16 row: zeros (consumers copy whole 64-byte row pieces)
+        const bool pq_out = EPI == EPI_RELU_AFFINE && PQOUT && p.c_sc;
+        if ((p.c_bf16 || pq_out) && col >= p.N && col < p.ldc) {     // pad columns of a bf16 / pair-format row: zeros (consumers copy whole 64-byte row pieces)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int lr = (tid >> 5) + 8 * j;
                 const int row = m0 + (lr >> 5) * 64 + rb * 32 + (lr & 31);
-                if (row < p.M) st4x(Cz, (size_t)row * p.ldc + col, make_float4(0.f, 0.f, 0.f, 0.f), 1);
+                if (row < p.M) {
+                    if (pq_out) btvae_pairs::pq_store4(reinterpret_cast<unsigned short*>(Cz + (size_t)row * p.ldc), col, make_float4(0.f, 0.f, 0.f, 0.f), 1.f);
+                    else st4x(Cz, (size_t)row * p.ldc + col, make_float4(0.f, 0.f, 0.f, 0.f), 1);
+                }
             }
         }
         if (col < p.N) {                               // N % 4 == 0 on this path: a 4-column group is in or out as a whole

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256 * NG, 2) void gemm_pq256(const GemmArgs p) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[h][i][j][e] = (acc[h][i][j][e] * ia) * ib;
         }
-        gemm_epilogue_staged<EPI, FMT == 1, 1>(p, acc[h], lds, m0 + g * 128, n0 + h * BN, tile_m * NG + g, zz);     // the launcher insists on 16-byte addressable outputs
+        gemm_epilogue_staged<EPI, FMT == 1, 1, FMT == 0, FMT == 0 && EPI == EPI_RELU_AFFINE>(p, acc[h], lds, m0 + g * 128, n0 + h * BN, tile_m * NG + g, zz);     // the launcher insists on 16-byte addressable outputs
     }
 }
 

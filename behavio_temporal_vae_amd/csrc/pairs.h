@@ -53,12 +53,13 @@ __device__ __forceinline__ void pq_store4(unsigned short* row, int c, const floa
     pq_encode2(v.x, v.y, s, P0, Q0);
     pq_encode2(v.z, v.w, s, P1, Q1);
     unsigned short* d = row + pq_col(c);
-    *reinterpret_cast<uint2*>(d) = make_uint2(P0, P1);
-    *reinterpret_cast<uint2*>(d + 16) = make_uint2(Q0, Q1);
+    const nat_u2 pv = {P0, P1}, qv = {Q0, Q1};        // native vectors: one 8-byte store each
+    *reinterpret_cast<nat_u2*>(d) = pv;
+    *reinterpret_cast<nat_u2*>(d + 16) = qv;
 }
 __device__ __forceinline__ float4 pq_load4(const unsigned short* row, int c, float inv) {
     const unsigned short* d = row + pq_col(c);
-    const uint2 P = *reinterpret_cast<const uint2*>(d), Q = *reinterpret_cast<const uint2*>(d + 16);
+    const nat_u2 P = *reinterpret_cast<const nat_u2*>(d), Q = *reinterpret_cast<const nat_u2*>(d + 16);
     float4 v;
     pq_decode2(P.x, Q.x, inv, v.x, v.y);
     pq_decode2(P.y, Q.y, inv, v.z, v.w);

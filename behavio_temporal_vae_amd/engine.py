@@ -515,6 +515,54 @@ def _like_rows(t: Optional[torch.Tensor], ref: torch.Tensor) -> Optional[torch.T
     return out
 
 
+EVAL_PAIRS = os.environ.get("BTVAE_EVAL_PAIRS", "1") != "0"
+# rows from which the eval-mode chains keep their activations in the pair format: the 256-wide kernel that reads it wants
+# several rounds of 256 x 256 tiles (at 25,000 rows x 1000 columns its 392 tiles are 1.5 rounds and the 128-wide kernel wins)
+EVAL_PAIRS_MIN_ROWS = int(os.environ.get("BTVAE_EVAL_PAIRS_MIN_ROWS", "65536"))
+
+
+class Pairs:
+    """A hidden activation in the pair format (csrc/pairs.h): ``data`` is an [M, N] fp32-typed view with a pitch that is a
+    multiple of 32 floats whose bytes hold, per row and 16 columns, the 16 high and the 16 low fp16 pieces of the values;
+    ``sc`` holds one power-of-two scale per 128 x 128 block.  The two-piece products take the pieces as they stand: eval-mode
+    chains (scoring, imputation) keep the activations between two non-residual units in this form."""
+
+    def __init__(self, data: torch.Tensor, sc: torch.Tensor):
+        self.data, self.sc = data, sc
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def float(self) -> torch.Tensor:
+        """The values as an fp32 matrix (tests, debugging)."""
+        M, N = self.data.shape
+        out = torch.empty(M, self.data.stride(0), device=self.data.device)
+        nv.call("btvae_pairs_decode", PR(self.data), self.data.stride(0), P(self.sc), P(out), out.stride(0), M, (N + 7) // 8 * 8)
+        return out[:, :N]
+
+
+def _eval_pairs_ok(M: int, N: int) -> bool:
+    """May an eval-mode unit with ``M`` rows of width ``N`` hand its output on in the pair format?  Two-piece mode, enough
+    rows, rows on a pitch that is a multiple of 16 floats, 16-byte column groups."""
+    pitch = -(-N // ROW_LINE_FLOATS) * ROW_LINE_FLOATS
+    return (EVAL_PAIRS and M >= EVAL_PAIRS_MIN_ROWS and _split_mode() == 2 and PRESPLIT_WEIGHTS and N % 4 == 0
+            and (PITCHED_ROWS or pitch == N))
+
+
+def _weight_image_pq(W: torch.Tensor, wmax: torch.Tensor) -> torch.Tensor:
+    """Stage images of ``W`` [N, K] for a product whose activation operand is in the pair format (``btvae_weight_image_pq``),
+    scaled by the maximum in ``wmax``.  A copy of ``W`` as it is now: made per pass."""
+    N, K = W.shape
+    img = torch.empty(nv.lib().btvae_weight_image_pq_bytes(N, K, 0), dtype=torch.uint8, device=W.device)
+    nv.call("btvae_weight_image_pq", P(W), K, N, K, 0, P(img), P(wmax))
+    return img
+
+
 def _linear_operands(lin: torch.nn.Linear, x):
     """(A, W, b, scale, shift) of ``lin`` applied to ``x``: a tensor as is, a Normed input through folded weights."""
     if not isinstance(x, Normed):
@@ -531,11 +579,13 @@ def _linear_operands(lin: torch.nn.Linear, x):
 
 
 def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_normed: bool = False,
-                 planes: Optional[Dict[torch.nn.Linear, torch.Tensor]] = None):
+                 planes: Optional[Dict[torch.nn.Linear, torch.Tensor]] = None, out_pairs: bool = False):
     """One Linear->ReLU->BatchNorm(->+x) unit (src/submodels.py:15-21,30-33) or a bare Linear.  ``x`` may be a
     ``Normed`` (train mode, non-residual units).  With ``keep_normed`` the caller promises that every consumer of
     the result is a plain (non-residual) Linear, and a BatchNorm unit without dropout returns a ``Normed``.
-    ``planes``: pre-split weights of the network made at the start of the pass (``_plan_planes``)."""
+    ``planes``: pre-split weights of the network made at the start of the pass (``_plan_planes``).
+    Eval mode: ``x`` may be a ``Pairs``; with ``out_pairs`` the caller promises that every consumer of the result is an
+    eval-mode non-residual unit, and the result is a ``Pairs`` when the unit can write one."""
     M, K = x.shape
     N = u.lin.out_features
     dev = x.device
@@ -630,6 +680,23 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         if u.bn is not None:
             scale, shift = torch.empty(N, device=dev), torch.empty(N, device=dev)
             nv.call("btvae_bn_fold_eval", P(u.bn.weight), P(u.bn.bias), P(u.bn.running_mean), P(u.bn.running_var), float(u.bn.eps), P(scale), P(shift), N)
+        pairs_in = isinstance(x, Pairs)
+        out_pairs = out_pairs and not u.residual and _eval_pairs_ok(M, N)
+        if pairs_in or out_pairs:
+            if u.residual:
+                raise RuntimeError("a residual unit needs its input as an fp32 matrix")
+            osc = torch.empty((M + 127) // 128, (N + 127) // 128, device=dev) if out_pairs else None
+            wmax = _planes_amax(wp, W)
+            if not out_pairs:
+                _track_output(out)                    # an fp32 result is the operand of a head product: its maximum from this epilogue
+            if pairs_in:
+                nv.call("btvae_linear_relu_affine_fwd_pairs", PR(x.data), x.data.stride(0), P(x.sc), None, P(_weight_image_pq(W, wmax)), P(wmax),
+                        P(b), P(scale), P(shift), PR(out), out.stride(0), P(osc), M, K, N)
+            else:
+                _operand_maxima(_amax(x), wmax, (id(u.lin.weight), "fwd"))
+                nv.call("btvae_linear_relu_affine_fwd_pairs", PR(x), x.stride(0), None, P(W), P(wp), None,
+                        P(b), P(scale), P(shift), PR(out), out.stride(0), P(osc), M, K, N)
+            return Pairs(out, osc) if out_pairs else out
         _operand_maxima(_amax(x), _planes_amax(wp, W), (id(u.lin.weight), "fwd"))
         _track_output(out)
         _bf16(a=x, out=out, aux=(x if u.residual else None,))
@@ -689,7 +756,9 @@ def net_forward(plan: NetPlan, x: torch.Tensor, train: bool, tape: Optional[NetT
             normed_ok = not plan.trunk[i + 1].residual
         else:
             normed_ok = all(not units[0].residual for units in plan.heads.values())
-        h = unit_forward(u, h, train, tape.trunk if tape is not None else None, keep_normed=train and normed_ok, planes=planes)
+        # eval mode: the result may stay in the pair format when everything that reads it is a non-residual hidden unit
+        pairs_ok = not train and normed_ok and (i + 1 < nt or all(len(units) > 1 for units in plan.heads.values()))
+        h = unit_forward(u, h, train, tape.trunk if tape is not None else None, keep_normed=train and normed_ok, planes=planes, out_pairs=pairs_ok)
     out, sqs = {}, {}
     for name, units in plan.heads.items():
         t = h
@@ -697,7 +766,8 @@ def net_forward(plan: NetPlan, x: torch.Tensor, train: bool, tape: Optional[NetT
         hidden = units[:-1]
         for i, u in enumerate(hidden):
             normed_ok = i + 1 == len(hidden) or not hidden[i + 1].residual
-            t = unit_forward(u, t, train, sv, keep_normed=train and normed_ok, planes=planes)
+            t = unit_forward(u, t, train, sv, keep_normed=train and normed_ok, planes=planes,
+                             out_pairs=not train and i + 1 < len(hidden) and not hidden[i + 1].residual)
         act, lo, hi = head_specs[name]
         val, dfac, sq, affine, hplanes = head_forward(units[-1], t, act, lo, hi, tape is not None, name in want_sq, planes)
         out[name] = val

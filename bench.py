@@ -272,9 +272,13 @@ def scoring_benchmark(dev, rank, world, n_profiles, K, chunk):
     tot, cnt = reduce_loglik(float(ll.double().sum().item()), n_profiles, device=dev)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    roof = _dominant_roofline(nv, model.gemm_precision,
-                              f"{KERNEL_NAME[model.gemm_precision]}<k-contig,k-contig,relu+affine(+residual),pre-split weight> M={M} N=K=1000 "
-                              "(decoder hidden Linear, eval mode)", M, 4.0 * (2.0 * M * 1000 + 1000 * 1000), "scoring_fwd")
+    from behavio_temporal_vae_amd import engine as E
+    pairs = E._eval_pairs_ok(M, 1000) and model.gemm_precision == "fp32_split2"
+    kname = ("gemm_pq256<relu+affine, 256 x 256 tile, two fp16 pieces, activations in and (trunk) out in the pair format, operands by global->LDS DMA>"
+             if pairs else f"{KERNEL_NAME[model.gemm_precision]}<k-contig,k-contig,relu+affine(+residual),pre-split weight>")
+    roof = _dominant_roofline(nv, model.gemm_precision, f"{kname} M={M} N=K=1000 (decoder hidden Linear, eval mode)", M,
+                              4.0 * (2.0 * M * 1000 + 1000 * 1000), "scoring_fwd_pairs" if pairs else "scoring_fwd")
+    roof["activations_in_pair_format"] = bool(pairs)
     nv.prof_filter(None, 0.0)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -166,7 +166,7 @@ int btvae_next_row_pitches(int ld_n, int ld_k);
  * the weight's stage images (btvae_weight_image_bf16: forward image at the start, dX image
  * btvae_weight_image_bf16_bytes(N, K, 0) bytes further; `which` 1 / 2 / 3 as for btvae_weight_planes; buffer of
  * _bytes(N, K, 0) + _bytes(N, K, 1) bytes, 16-byte aligned) runs on a 256-wide kernel that copies both operands
- * global -> LDS by DMA (633 TFLOP/s at M = 65536, N = K = 1000 against 360 for fp32 tensors); without images the
+ * global -> LDS by DMA (780 TFLOP/s at M = 65536, N = K = 1000 against 360 for fp32 tensors); without images the
  * 128-wide kernel reads the fp32 weight. */
 int btvae_next_bf16(int mask);
 long long btvae_weight_image_bf16_bytes(int N, int K, int transpose);
@@ -174,6 +174,30 @@ int btvae_weight_image_bf16(const float* W, int ldw, int N, int K, int which, vo
 /* The same for `count` contiguous matrices (host arrays of length count) in one launch per 32 images. */
 int btvae_weight_image_bf16_multi(const float* const* W, const int* N, const int* K, void* const* image, const int* which,
                                   int count, void* stream);
+
+/* Pair-format activations (mode 3, eval-mode chains; no counterpart in the reference, whose tensors are fp32:
+ * src/submodels.py:28-35).  A matrix X[M][N] in the pair format occupies the bytes of the fp32 matrix of the same pitch
+ * (a multiple of 16 floats): per row and 16 columns 64 bytes = 16 fp16 high pieces p = fp16(s x), then 16 low pieces
+ * q = fp16(s x - p), with one power-of-two scale s per 128 x 128 block taken from the block's own maximum
+ * (sc[ceil(M/128)][ceil(N/128)] floats).  x = (p + q) / s to 2^-23 of its magnitude for elements within 2^17 of their
+ * block's maximum; the pieces are the operands of the two-piece products as they stand, so a consumer needs no arithmetic
+ * on them and no per-tensor maximum.  Columns between N and the end of the last 16-group are zeros.
+ * btvae_pairs_encode / _decode convert whole matrices (N % 8 == 0; in place when the pitches agree).
+ * btvae_weight_image_pq writes the stage images of W[R][C] (transpose 0: output columns = rows of W, the forward
+ * products) that the 256-wide kernel copies into LDS; *amax = max |W| (a slot made by btvae_absmax), buffer of
+ * btvae_weight_image_pq_bytes(R, C, transpose) bytes, 16-byte aligned.
+ * btvae_linear_relu_affine_fwd_pairs is btvae_linear_relu_affine_fwd_pw_ld without add-in, for either format on either
+ * side: x_sc NULL = X is fp32 (Wsplit = the weight's fp16 planes or NULL, operand maxima through
+ * btvae_gemm_operand_maxima), else X is in the pair format with block scales x_sc and Wsplit = the weight's stage
+ * images made with the maximum *wmax; out_sc NULL = Out is fp32, else Out is written in the pair format (ldo % 16 == 0)
+ * and out_sc receives its block scales.  Pitches count floats in both formats. */
+int btvae_pairs_encode(const float* X, int ldx, void* P, int ldp, float* sc, int M, int N, void* stream);
+int btvae_pairs_decode(const void* P, int ldp, const float* sc, float* X, int ldx, int M, int N, void* stream);
+long long btvae_weight_image_pq_bytes(int R, int C, int transpose);
+int btvae_weight_image_pq(const float* W, int ldw, int R, int C, int transpose, void* image, const float* amax, void* stream);
+int btvae_linear_relu_affine_fwd_pairs(const void* X, int ldx, const float* x_sc, const float* W, const void* Wsplit, const float* wmax,
+                                       const float* b, const float* scale, const float* shift, void* Out, int ldo, float* out_sc,
+                                       int M, int K, int N, void* stream);
 
 /* ---- BatchNorm1d (torch.nn.BatchNorm1d as used at src/submodels.py:20-21,50) ---- */
 int btvae_strip_chunks(int M);

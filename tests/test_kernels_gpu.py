@@ -1203,3 +1203,93 @@ def test_linear_products_at_benchmark_size(dev, gemm_mode):
     # sums of 65536 unit-variance products (result rms 256) accumulated in fp32, 4096 terms per split: every add rounds
     # a running sum of magnitude ~64, a random walk of a few 1e-4 per split; 1.2e-5 of the result's rms is the bound
     close(dW, dY.double().t() @ X.double(), 2e-6, 1.2e-5 * math.sqrt(M), "wgrad")
+
+
+@pytest.mark.parametrize("M,K0,H", [(300, 28, 200), (520, 52, 72), (16500, 28, 1000)])
+def test_pair_format_eval_chain(dev, M, K0, H):
+    """Eval-mode units with their activations in the pair format (``btvae_linear_relu_affine_fwd_pairs``, csrc/pairs.h):
+    fp32 input -> pairs, pairs -> pairs, pairs -> fp32, each against fp64 on the values it was given; 128-row workgroups
+    and (M = 16,500) 256-row ones with a row group wholly past the matrix; pad columns of a pair-format row come back as
+    zeros; whole-matrix encode / decode.  Tolerance: the two-piece product's (2e-6 relative + 2e-6 sqrt(K) of the operand
+    scale) plus, for a pair-format output, 2^-22 of its block's maximum."""
+    nv.set_gemm_precision("fp32_split2")
+    try:
+        L = nv.lib()
+        g = torch.Generator().manual_seed(M + H)
+        ld = (H + 31) // 32 * 32
+        X0 = torch.randn(M, K0, generator=g).to(dev)
+        Ws = [(torch.randn(H, K0, generator=g) / math.sqrt(K0)).to(dev), (torch.randn(H, H, generator=g) / math.sqrt(H)).to(dev),
+              (torch.randn(H, H, generator=g) / math.sqrt(H)).to(dev)]
+        bs = [(0.3 * torch.randn(H, generator=g)).to(dev) for _ in range(3)]
+        scs = [(0.5 + torch.rand(H, generator=g)).to(dev) for _ in range(3)]
+        shs = [(0.2 * torch.randn(H, generator=g)).to(dev) for _ in range(3)]
+
+        def slot(t):
+            s = torch.zeros(2, device=dev)
+            nv.call("btvae_absmax", P(t), t.numel(), P(s))
+            return s
+
+        def ref(x64, i):
+            return torch.relu(x64 @ Ws[i].double().t() + bs[i].double()) * scs[i].double() + shs[i].double()
+
+        def pair_buffer():
+            return torch.full((M, ld), float("nan"), device=dev), torch.full(((M + 127) // 128, (H + 127) // 128), float("nan"), device=dev)
+
+        def decode(buf, sc, width):
+            out = torch.empty(M, ld, device=dev)
+            nv.call("btvae_pairs_decode", P(buf), ld, P(sc), P(out), ld, M, width)
+            return out
+
+        # unit 1: fp32 in, pairs out (128-wide two-piece kernel, weight as fp16 planes)
+        xmax, wmax = slot(X0), slot(Ws[0])
+        planes = torch.empty(L.btvae_weight_planes_elems(H, K0), dtype=torch.int16, device=dev)
+        nv.call("btvae_weight_planes_f16", P(Ws[0]), K0, H, K0, P(planes), 1, P(wmax))
+        y1, s1 = pair_buffer()
+        L.btvae_gemm_operand_maxima(P(xmax), P(wmax))
+        nv.call("btvae_linear_relu_affine_fwd_pairs", P(X0), K0, None, P(Ws[0]), P(planes), None, P(bs[0]), P(scs[0]), P(shs[0]),
+                P(y1), ld, P(s1), M, K0, H)
+        torch.cuda.synchronize()
+        assert torch.isfinite(s1).all() and (s1 > 0).all()
+        full = decode(y1, s1, ld)                       # every column up to the pitch: the pad columns must decode to zero
+        assert torch.equal(full[:, H:], torch.zeros_like(full[:, H:])), "pad columns of a pair-format row"
+        r1 = ref(X0.double(), 0)
+        blockmax = float(r1.abs().max())
+        close(full[:, :H], r1, 2e-6, 2e-6 * math.sqrt(K0) * float(X0.abs().max()) + 2.0 ** -22 * blockmax, "fp32 -> pairs")
+
+        # unit 2: pairs in, pairs out (256-wide DMA-fed kernel)
+        x2 = full[:, :H].double()                       # the values the pair-format operand holds
+        wmax2 = slot(Ws[1])
+        img = torch.empty(L.btvae_weight_image_pq_bytes(H, H, 0), dtype=torch.uint8, device=dev)
+        nv.call("btvae_weight_image_pq", P(Ws[1]), H, H, H, 0, P(img), P(wmax2))
+        y2, s2 = pair_buffer()
+        nv.call("btvae_linear_relu_affine_fwd_pairs", P(y1), ld, P(s1), None, P(img), P(wmax2), P(bs[1]), P(scs[1]), P(shs[1]),
+                P(y2), ld, P(s2), M, H, H)
+        full2 = decode(y2, s2, ld)
+        assert torch.equal(full2[:, H:], torch.zeros_like(full2[:, H:]))
+        r2 = ref(x2, 1)
+        close(full2[:, :H], r2, 2e-6, 2e-6 * math.sqrt(H) * float(x2.abs().max()) + 2.0 ** -22 * float(r2.abs().max()), "pairs -> pairs")
+
+        # unit 3: pairs in, fp32 out
+        wmax3 = slot(Ws[2])
+        img3 = torch.empty(L.btvae_weight_image_pq_bytes(H, H, 0), dtype=torch.uint8, device=dev)
+        nv.call("btvae_weight_image_pq", P(Ws[2]), H, H, H, 0, P(img3), P(wmax3))
+        y3 = torch.full((M, ld), float("nan"), device=dev)
+        nv.call("btvae_linear_relu_affine_fwd_pairs", P(y2), ld, P(s2), None, P(img3), P(wmax3), P(bs[2]), P(scs[2]), P(shs[2]),
+                P(y3), ld, None, M, H, H)
+        x3 = full2[:, :H].double()
+        close(y3[:, :H], ref(x3, 2), 2e-6, 2e-6 * math.sqrt(H) * float(x3.abs().max()), "pairs -> fp32")
+
+        # whole-matrix conversion: encode, decode, compare (22 bits below each block's maximum)
+        Xe = torch.zeros(M, ld, device=dev)
+        Xe[:, :H] = torch.randn(M, H, generator=g).to(dev) * torch.logspace(-3, 3, H).to(dev)      # block maxima spread over six decades
+        Pe, se = pair_buffer()
+        Hc = (H + 7) // 8 * 8
+        nv.call("btvae_pairs_encode", P(Xe), ld, P(Pe), ld, P(se), M, Hc)
+        back = decode(Pe, se, Hc)
+        for bi in range((M + 127) // 128):
+            for bj in range((H + 127) // 128):
+                blk = Xe[bi * 128:(bi + 1) * 128, bj * 128:min((bj + 1) * 128, H)]
+                got = back[bi * 128:(bi + 1) * 128, bj * 128:min((bj + 1) * 128, H)]
+                assert float((got - blk).abs().max()) <= 2.0 ** -22 * float(blk.abs().max()) + 1e-30, (bi, bj)
+    finally:
+        nv.set_gemm_precision("fp32")

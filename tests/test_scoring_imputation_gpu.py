@@ -558,3 +558,45 @@ def test_collection_scripts_end_to_end(dev, tmp_path):
     # second call without overwrite skips the folder
     args.overwrite = False
     assert load("collect_imputation_results").main(args) == {}
+
+
+def test_eval_chain_in_pair_format_equals_fp32_chain(dev):
+    """The eval-mode chains keep their hidden activations in the pair format from a row count on (``engine.EVAL_PAIRS_MIN_ROWS``):
+    with the threshold at zero the importance-weighted scoring of a gipuzkoa-shaped model must reproduce the fp32-activation
+    chain (the pieces the products multiply are the same ones: 1e-5 on the per-draw log-likelihoods, which are O(100))."""
+    from behavio_temporal_vae_amd import engine as E, testing_lib
+    from behavio_temporal_vae_amd.vae_models import CVAE
+    cfg = {"latent_dim": 24, "distribution_dict": {
+        "posterior": {"dist_type": "normal", "sigma_lim": 0.05, "mu_upper_lim": 5.0, "mu_lower_lim": -5.0, "num_neurons": 200,
+                      "num_hidden_layers": 2, "dropout": True, "dropout_rate": 0.2, "batch_normalization": True},
+        "likelihood": {"dist_type": "dict-gauss", "vocab_size": 100, "sigma_lim": 1e-6, "marginal_std_lim": 0.05, "mu_lower_lim": -3,
+                       "num_neurons": 200, "num_hidden_layers": 3, "dropout": True, "dropout_rate": 0.2, "batch_normalization": True}}}
+
+    class C4:
+        cond_dim = 4
+    torch.manual_seed(5)
+    m = CVAE(input_dim=24, conditioner=C4(), **cfg).to(dev).eval()
+    assert m.gemm_precision == "fp32_split2"
+    N, K = 300, 40
+    gen = torch.Generator().manual_seed(6)
+    x, c = torch.randn(N, 24, generator=gen).to(dev), torch.randn(N, 4, generator=gen).to(dev)
+    eps = torch.randn(K, N, 24, generator=gen).to(dev)
+    keep = E.EVAL_PAIRS_MIN_ROWS
+    seen = []
+    orig = E.Pairs.__init__
+
+    def spy(self, data, sc):
+        seen.append(tuple(data.shape))
+        orig(self, data, sc)
+    try:
+        E.EVAL_PAIRS_MIN_ROWS = 1 << 30
+        a, ra, _ = testing_lib.iw_loglikelihood_device(m, x, c, K, mc_sample_batch_size=20, eps=eps, return_rlls=True)
+        E.EVAL_PAIRS_MIN_ROWS = 0
+        E.Pairs.__init__ = spy
+        b, rb, _ = testing_lib.iw_loglikelihood_device(m, x, c, K, mc_sample_batch_size=20, eps=eps, return_rlls=True)
+    finally:
+        E.EVAL_PAIRS_MIN_ROWS = keep
+        E.Pairs.__init__ = orig
+    assert (N * 20, 200) in seen, seen              # the decoder's trunk handed pair-format activations on
+    assert torch.allclose(ra, rb, rtol=1e-6, atol=1e-5 * float(ra.abs().max()))
+    assert torch.allclose(a, b, rtol=1e-6, atol=1e-5 * float(a.abs().max()))
