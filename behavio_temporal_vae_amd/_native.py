@@ -42,7 +42,7 @@ _SIGS = {
     "btvae_pairs_encode": [P, I, P, I, P, I, I, P],
     "btvae_pairs_decode": [P, I, P, P, I, I, I, P],
     "btvae_weight_image_pq": [P, I, I, I, I, P, P, P],
-    "btvae_linear_relu_affine_fwd_pairs": [P, I, P, P, P, P, P, P, P, P, I, P, I, I, I, P],
+    "btvae_linear_relu_affine_fwd_pairs": [P, I, P, P, P, P, P, P, P, I, P, I, P, I, I, I, P],
     "btvae_weight_image_bf16_multi": [P, P, P, P, P, I, P],
     "btvae_linear_head_fwd": [P, I, P, P, I, F, F, P, P, P, I, I, I, P],
     "btvae_linear_head_fwd_ws": [P, I, P, P, I, F, F, P, P, P, P, LL, I, I, I, P],

@@ -760,7 +760,7 @@ int launch_pq256(GemmArgs& a, int groups, hipStream_t s, const char* what) {
     a.a_vec = a.b_vec = 1;
     a.c_vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && aligned16(a.C) && (!a.R || (a.ldr % 4 == 0 && aligned16(a.R)));
     BTVAE_REQUIRE(!a.c_sc || (EPI == EPI_RELU_AFFINE && a.c_vec), "%s: pair-format output needs a 16-byte addressable output", what);
-    BTVAE_REQUIRE(EPI != EPI_RELU_AFFINE || !a.R, "%s: no add-in on a pair-format operand", what);
+    BTVAE_REQUIRE(EPI != EPI_RELU_AFFINE || !a.R || a.r_sc, "%s: an add-in of this kernel is in the pair format", what);
     a.kchunk = a.bp_tiles * 16;
 #ifdef BTVAE_PQ_ABLATE
     { const char* e = getenv("BTVAE_PQ_ABLATE"); a.lde = e ? atoi(e) : 0; }
@@ -1122,15 +1122,17 @@ BTVAE_API int btvae_linear_relu_affine_fwd_pw_ld(const float* X, int ldx, const 
     return launch<LAY_K, LAY_K, EPI_RELU_AFFINE>(a, 1, (hipStream_t)stream, "linear_relu_affine_fwd", true);
 }
 
-// The same unit with its activations in the pair format (eval-mode chains of the two-piece mode; no add-in).
+// The same unit with its activations in the pair format (eval-mode chains of the two-piece mode); `residual`: Out += X
+// (X in the pair format, K == N).
 //   X: fp32 (x_sc null; W's fp16 planes in Wsplit, operand maxima through btvae_gemm_operand_maxima as for the call above)
 //      or pairs (x_sc = its block scales; Wsplit = btvae_weight_image_pq image made with the maximum *wmax);
 //   Out: fp32 (out_sc null) or pairs (out_sc[ceil(M/128)][ceil(N/128)] receives the block scales; ldo % 16 == 0, pad columns zeroed).
 // Pitches count floats in both formats (a pair-format row has the bytes of the fp32 row it replaces).
 BTVAE_API int btvae_linear_relu_affine_fwd_pairs(const void* X, int ldx, const float* x_sc, const float* W, const void* Wsplit, const float* wmax,
-                                                 const float* b, const float* scale, const float* shift, void* Out, int ldo, float* out_sc,
+                                                 const float* b, const float* scale, const float* shift, int residual, void* Out, int ldo, float* out_sc,
                                                  int M, int K, int N, void* stream) {
     BTVAE_REQUIRE(b, "linear_relu_affine_fwd_pairs: null bias");
+    BTVAE_REQUIRE(!residual || (x_sc && K == N), "linear_relu_affine_fwd_pairs: the residual form adds a pair-format X of the output's width");
     BTVAE_REQUIRE(ldo >= N && (!out_sc || (ldo % 16 == 0 && N % 4 == 0 && aligned16(Out))),
                   "linear_relu_affine_fwd_pairs: pair-format output needs N %% 4 == 0, a 16-byte aligned base and a pitch that is a multiple of 16 (N %d, pitch %d)", N, ldo);
     GemmArgs a{}; a.C = (float*)Out; a.ldc = ldo; a.M = M; a.N = N; a.K = K;
@@ -1140,9 +1142,10 @@ BTVAE_API int btvae_linear_relu_affine_fwd_pairs(const void* X, int ldx, const f
         BTVAE_REQUIRE(g_precision.load(std::memory_order_relaxed) == 3, "linear_relu_affine_fwd_pairs: pair-format operands belong to the two-piece mode");
         BTVAE_REQUIRE(Wsplit && wmax, "linear_relu_affine_fwd_pairs: a pair-format operand needs the weight's stage images and its maximum");
         a.A = (const float*)X; a.lda = ldx; a.a_sc = x_sc; a.Bp = (const unsigned short*)Wsplit; a.amax_b = wmax;
+        if (residual) { a.R = (const float*)X; a.ldr = ldx; a.r_sc = x_sc; }
         const int wide_tiles = ((M + 255) / 256) * ((N + QN - 1) / QN);
         static const int forced = [] { const char* e = getenv("BTVAE_PQ256_GROUPS"); return e ? atoi(e) : 0; }();   // tuning: 1 / 2 rows of 128 per workgroup
-        const int groups = forced == 1 ? 1 : (wide_tiles >= 256 ? 2 : 1);
+        const int groups = (forced == 1 || residual) ? 1 : (wide_tiles >= 256 ? 2 : 1);     // the residual form stages its add-in in LDS the 256-row workgroup lacks
         return launch_pq256<EPI_RELU_AFFINE>(a, groups, (hipStream_t)stream, "linear_relu_affine_fwd_pairs");
     }
     BTVAE_REQUIRE(W, "linear_relu_affine_fwd_pairs: null weight");

@@ -49,6 +49,9 @@ struct GemmArgs {
     // EPI_RELU_AFFINE: non-null = the output is written in that format, one block per 128 x 128 tile, its scales to
     // c_sc[row tile][c_scn] (ldc counts floats: a pair-format row has the bytes of the fp32 row it replaces); no add-in then
     float* c_sc; int c_scn;
+    // ... and non-null = the add-in R is in that format too (its block scales; R has the output's shape, so the tile's block
+    // of R is block (row tile, column tile) of r_sc[.][c_scn])
+    const float* r_sc;
     // hidden activations / gradients stored as bf16 (the bf16 mode's storage format; leading dimensions then count bf16
     // elements): the output C, and the add-in R together with the BatchNorm input bn_y.  Staged epilogue only.
     int c_bf16, r_bf16;
@@ -111,6 +114,12 @@ __device__ __forceinline__ void head_value(const GemmArgs& p, float raw, float& 
 // the thread index used here is the one inside the group.
 constexpr int EPL = 132;
 
+// 16 bytes per lane global -> LDS without passing through registers: lane i's piece lands at `l` + 16 i (`l` wave-uniform)
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
 __device__ __forceinline__ float4 ld4(const float* q) { return *reinterpret_cast<const float4*>(q); }
 __device__ __forceinline__ void st4(float* q, const float4 v) { *reinterpret_cast<float4*>(q) = v; }
 // AUX16: the matrices read here (add-in, BatchNorm input) are known to hold bf16 (p.r_bf16 set): they wait for their use
@@ -118,8 +127,9 @@ __device__ __forceinline__ void st4(float* q, const float4 v) { *reinterpret_cas
 // ROWS: how many of a thread's eight rows are read from the LDS image before their stores are issued on a row tile inside
 // the matrix: 8; fewer in the kernels whose 128 accumulator registers leave no room for eight rows in flight; 1 = every
 // tile takes the row-by-row path of the edge tiles (no second copy of the store code either).
-// PQOUT: the kernel may be asked for pair-format output (p.c_sc; EPI_RELU_AFFINE only).  NOADD: it is never given an add-in.
-template <int EPI, bool AUX16 = false, int ROWS = 8, bool PQOUT = true, bool NOADD = false>
+// PQOUT: the kernel may be asked for pair-format output (p.c_sc; EPI_RELU_AFFINE only).  ADDIN: 0 = an add-in is fp32 / bf16
+// or (with PQOUT) in the pair format, as the arguments say; 1 = the kernel is never given one; 2 = only pair-format ones.
+template <int EPI, bool AUX16 = false, int ROWS = 8, bool PQOUT = true, int ADDIN = 0>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[2][2], float* lds, int m0, int n0, int tile_m, int zz) {
     const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
@@ -180,7 +190,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             m = wave_max(m);
             if (lane == 0) red[wid] = m;
             __syncthreads();
-            pq_s = btvae_pairs::pq_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+            float bound = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            // a pair-format add-in: its values are below 2^15 / (its block's scale), which bounds the sum to within a factor of two
+            if (p.R && p.r_sc && m0 < p.M) bound += 32768.f * btvae_pairs::pq_inv(p.r_sc[(size_t)(m0 >> 7) * p.c_scn + (n0 >> 7)]);
+            pq_s = btvae_pairs::pq_scale_for(bound);
             if (tid == 0 && m0 < p.M) p.c_sc[(size_t)(m0 >> 7) * p.c_scn + (n0 >> 7)] = pq_s;
         }
     }
@@ -188,8 +201,32 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
     // EPI_RELU_STATS on a row tile that lies inside the matrix (uniform): every row counts, so the statistics need no
     // per-element bounds test -- the first element is the shift, the count is a constant (invalid columns get count 0)
     const bool rows_full = EPI == EPI_RELU_STATS && m0 + BM <= p.M;
+    // ADDIN == 2: the add-in (pair format, p.r_sc) reaches the rows through LDS -- 64 rows x 512 bytes behind the image and the
+    // reduction scratch (another 32 KiB of `lds`), filled by DMA while the accumulators go into the image: no registers held
+    // across the loads next to 128 accumulators
+    constexpr bool RLDS = EPI == EPI_RELU_AFFINE && PQOUT && ADDIN == 2;
+    char* rlds = reinterpret_cast<char*>(lds) + (64 * EPL + 6 * 128) * 4;
+    float rinv = 1.f;
+    if constexpr (RLDS) {
+        if (p.R) rinv = btvae_pairs::pq_inv(p.r_sc[(size_t)(min(m0, p.M - 1) >> 7) * p.c_scn + (n0 >> 7)]);
+    }
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
+        if constexpr (RLDS) {
+            if (p.R) {                                 // uniform; wave `wid` moves image rows 16 wid .. + 15, two rows per instruction
+                // source = tile base (uniform) + 32-bit lane offset; rows past the matrix read its last row, columns past the
+                // pitch its last 16 bytes (neither is used)
+                const char* rbase = reinterpret_cast<const char*>(p.R) + (((size_t)min(m0, p.M - 1) * p.ldr) << 2);
+                const unsigned cbytes = (unsigned)min(n0 * 4 + (lane & 31) * 16, p.ldr * 4 - 16);
+                const int rlast = p.M - 1 - m0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int il = wid * 16 + i * 2 + (lane >> 5);
+                    const int lr = (il >> 5) * 64 + rb * 32 + (il & 31);
+                    glds16(rbase + (cbytes + ((unsigned)(max(min(lr, rlast), 0) * p.ldr) << 2)), rlds + (wid * 16 + i * 2) * 512);
+                }
+            }
+        }
         // registers -> LDS image; local row = wr*32 + (r&3) + 8(r>>2) + 4*lh
         auto to_lds = [&](auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
@@ -222,6 +259,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             }
         };
         if (rows_full) to_lds(std::true_type{}); else to_lds(std::false_type{});
+        if constexpr (RLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the add-in have landed
         __syncthreads();
         if (!p.c_vec) {                                // uniform
             if constexpr (EPI != EPI_GSTATS && EPI != EPI_BNBWD) {       // those two are launched on 16-byte addressable outputs only
@@ -270,7 +308,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
         const int mlast = p.M - 1 - m0;                 // last valid row of the tile (>= 127 inside the matrix); uniform
         const int shc = p.c_bf16 ? 1 : 2;
         auto lrow = [&](int j) { return (j >> 2) * 64 + rb * 32 + 8 * (j & 3) + tr; };
-        constexpr bool USE_R = !NOADD && (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_RELU_AFFINE || EPI == EPI_GSTATS || EPI == EPI_BNBWD);
+        constexpr bool USE_R = ADDIN != 1 && (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_RELU_AFFINE || EPI == EPI_GSTATS || EPI == EPI_BNBWD);
         constexpr bool USE_Y = EPI == EPI_GSTATS || EPI == EPI_BNBWD;
         constexpr bool USE_E = EPI == EPI_MUL;
         typedef typename std::conditional<AUX16, uint2, float4>::type aux_t;
@@ -319,7 +357,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
         };
         const bool rbf = p.r_bf16 != 0;
         if constexpr (USE_Y) load_rows(yq, p.bn_y, p.ldc, rbf);
-        if constexpr (USE_R) { if (p.R) load_rows(rq, p.R, p.ldr, rbf); }
+        if constexpr (USE_R && ADDIN != 2) { if (p.R) load_rows(rq, p.R, p.ldr, rbf); }
         if constexpr (USE_E) {
             load_rows(eq1, p.E1, p.lde, false);
             load_rows(eq2, p.E2, p.lde, false);
@@ -331,7 +369,16 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
                 return reinterpret_cast<char*>(base) + (((size_t)m0 * p.ldc + n0) << sh) + ((unsigned)(lr * p.ldc + c4) << sh);
             };
             char* o = out_at(Cz, shc);
-            if (USE_R && p.R) { const float4 q = wide4(rq[j], rbf); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            if (USE_R && p.R) {
+                float4 q;
+                if constexpr (RLDS) {                  // the add-in's row of the half-block staged in LDS: high pieces, low pieces 32 bytes on
+                    const char* rr = rlds + (tr + 8 * j) * 512 + (btvae_pairs::pq_col(c4) << 1);
+                    const nat_u2 hi = *reinterpret_cast<const nat_u2*>(rr), lo = *reinterpret_cast<const nat_u2*>(rr + 32);
+                    btvae_pairs::pq_decode2(hi.x, lo.x, rinv, q.x, q.y);
+                    btvae_pairs::pq_decode2(hi.y, lo.y, rinv, q.z, q.w);
+                } else q = wide4(rq[j], rbf);
+                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+            }
             if (EPI == EPI_PLAIN || EPI == EPI_BIAS) {
                 st4b(o, v, p.c_bf16);
             } else if (EPI == EPI_RELU_STATS || EPI == EPI_RELU_AFFINE) {

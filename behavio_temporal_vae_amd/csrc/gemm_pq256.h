@@ -35,10 +35,6 @@ __device__ __host__ __forceinline__ int q_off(int r, int c) { return r * QROW + 
 
 typedef _Float16 qf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
 
 // NG groups of four waves (block tile 128 NG x 256), QNST stages in the ring.
 // FMT 0: pair format, 16 k per stage (a row's 64-byte piece = high and low fp16 pieces of 16 k), three f16 MFMAs per
@@ -215,7 +211,7 @@ __global__ __launch_bounds__(256 * NG, 2) void gemm_pq256(const GemmArgs p) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[h][i][j][e] = (acc[h][i][j][e] * ia) * ib;
         }
-        gemm_epilogue_staged<EPI, FMT == 1, 1, FMT == 0, FMT == 0 && EPI == EPI_RELU_AFFINE>(p, acc[h], lds, m0 + g * 128, n0 + h * BN, tile_m * NG + g, zz);     // the launcher insists on 16-byte addressable outputs
+        gemm_epilogue_staged<EPI, FMT == 1, 1, FMT == 0, (FMT == 0 && EPI == EPI_RELU_AFFINE) ? 2 : 0>(p, acc[h], lds, m0 + g * 128, n0 + h * BN, tile_m * NG + g, zz);     // the launcher insists on 16-byte addressable outputs
     }
 }
 

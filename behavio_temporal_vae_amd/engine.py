@@ -585,7 +585,7 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
     the result is a plain (non-residual) Linear, and a BatchNorm unit without dropout returns a ``Normed``.
     ``planes``: pre-split weights of the network made at the start of the pass (``_plan_planes``).
     Eval mode: ``x`` may be a ``Pairs``; with ``out_pairs`` the caller promises that every consumer of the result is an
-    eval-mode non-residual unit, and the result is a ``Pairs`` when the unit can write one."""
+    eval-mode hidden unit, and the result is a ``Pairs`` when the unit can write one."""
     M, K = x.shape
     N = u.lin.out_features
     dev = x.device
@@ -681,21 +681,21 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
             scale, shift = torch.empty(N, device=dev), torch.empty(N, device=dev)
             nv.call("btvae_bn_fold_eval", P(u.bn.weight), P(u.bn.bias), P(u.bn.running_mean), P(u.bn.running_var), float(u.bn.eps), P(scale), P(shift), N)
         pairs_in = isinstance(x, Pairs)
-        out_pairs = out_pairs and not u.residual and _eval_pairs_ok(M, N)
+        out_pairs = out_pairs and (pairs_in or not u.residual) and _eval_pairs_ok(M, N)      # a residual unit adds a pair-format input only
         if pairs_in or out_pairs:
-            if u.residual:
-                raise RuntimeError("a residual unit needs its input as an fp32 matrix")
+            if u.residual and not pairs_in:
+                raise RuntimeError("a residual unit in the pair-format chain needs its input in that format")
             osc = torch.empty((M + 127) // 128, (N + 127) // 128, device=dev) if out_pairs else None
             wmax = _planes_amax(wp, W)
             if not out_pairs:
                 _track_output(out)                    # an fp32 result is the operand of a head product: its maximum from this epilogue
             if pairs_in:
                 nv.call("btvae_linear_relu_affine_fwd_pairs", PR(x.data), x.data.stride(0), P(x.sc), None, P(_weight_image_pq(W, wmax)), P(wmax),
-                        P(b), P(scale), P(shift), PR(out), out.stride(0), P(osc), M, K, N)
+                        P(b), P(scale), P(shift), 1 if u.residual else 0, PR(out), out.stride(0), P(osc), M, K, N)
             else:
                 _operand_maxima(_amax(x), wmax, (id(u.lin.weight), "fwd"))
                 nv.call("btvae_linear_relu_affine_fwd_pairs", PR(x), x.stride(0), None, P(W), P(wp), None,
-                        P(b), P(scale), P(shift), PR(out), out.stride(0), P(osc), M, K, N)
+                        P(b), P(scale), P(shift), 0, PR(out), out.stride(0), P(osc), M, K, N)
             return Pairs(out, osc) if out_pairs else out
         _operand_maxima(_amax(x), _planes_amax(wp, W), (id(u.lin.weight), "fwd"))
         _track_output(out)
@@ -756,8 +756,9 @@ def net_forward(plan: NetPlan, x: torch.Tensor, train: bool, tape: Optional[NetT
             normed_ok = not plan.trunk[i + 1].residual
         else:
             normed_ok = all(not units[0].residual for units in plan.heads.values())
-        # eval mode: the result may stay in the pair format when everything that reads it is a non-residual hidden unit
-        pairs_ok = not train and normed_ok and (i + 1 < nt or all(len(units) > 1 for units in plan.heads.values()))
+        # eval mode: the result may stay in the pair format when everything that reads it is a hidden unit (a residual one
+        # adds it in that format)
+        pairs_ok = not train and (i + 1 < nt or all(len(units) > 1 for units in plan.heads.values()))
         h = unit_forward(u, h, train, tape.trunk if tape is not None else None, keep_normed=train and normed_ok, planes=planes, out_pairs=pairs_ok)
     out, sqs = {}, {}
     for name, units in plan.heads.items():
@@ -767,7 +768,7 @@ def net_forward(plan: NetPlan, x: torch.Tensor, train: bool, tape: Optional[NetT
         for i, u in enumerate(hidden):
             normed_ok = i + 1 == len(hidden) or not hidden[i + 1].residual
             t = unit_forward(u, t, train, sv, keep_normed=train and normed_ok, planes=planes,
-                             out_pairs=not train and i + 1 < len(hidden) and not hidden[i + 1].residual)
+                             out_pairs=not train and i + 1 < len(hidden))
         act, lo, hi = head_specs[name]
         val, dfac, sq, affine, hplanes = head_forward(units[-1], t, act, lo, hi, tape is not None, name in want_sq, planes)
         out[name] = val

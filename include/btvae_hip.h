@@ -186,8 +186,8 @@ int btvae_weight_image_bf16_multi(const float* const* W, const int* N, const int
  * btvae_weight_image_pq writes the stage images of W[R][C] (transpose 0: output columns = rows of W, the forward
  * products) that the 256-wide kernel copies into LDS; *amax = max |W| (a slot made by btvae_absmax), buffer of
  * btvae_weight_image_pq_bytes(R, C, transpose) bytes, 16-byte aligned.
- * btvae_linear_relu_affine_fwd_pairs is btvae_linear_relu_affine_fwd_pw_ld without add-in, for either format on either
- * side: x_sc NULL = X is fp32 (Wsplit = the weight's fp16 planes or NULL, operand maxima through
+ * btvae_linear_relu_affine_fwd_pairs is btvae_linear_relu_affine_fwd_pw_ld for either format on either side (residual != 0:
+ * the unit's input, in the pair format and of the output's width, is added to the result): x_sc NULL = X is fp32 (Wsplit = the weight's fp16 planes or NULL, operand maxima through
  * btvae_gemm_operand_maxima), else X is in the pair format with block scales x_sc and Wsplit = the weight's stage
  * images made with the maximum *wmax; out_sc NULL = Out is fp32, else Out is written in the pair format (ldo % 16 == 0)
  * and out_sc receives its block scales.  Pitches count floats in both formats. */
@@ -196,8 +196,8 @@ int btvae_pairs_decode(const void* P, int ldp, const float* sc, float* X, int ld
 long long btvae_weight_image_pq_bytes(int R, int C, int transpose);
 int btvae_weight_image_pq(const float* W, int ldw, int R, int C, int transpose, void* image, const float* amax, void* stream);
 int btvae_linear_relu_affine_fwd_pairs(const void* X, int ldx, const float* x_sc, const float* W, const void* Wsplit, const float* wmax,
-                                       const float* b, const float* scale, const float* shift, void* Out, int ldo, float* out_sc,
-                                       int M, int K, int N, void* stream);
+                                       const float* b, const float* scale, const float* shift, int residual, void* Out, int ldo,
+                                       float* out_sc, int M, int K, int N, void* stream);
 
 /* ---- BatchNorm1d (torch.nn.BatchNorm1d as used at src/submodels.py:20-21,50) ---- */
 int btvae_strip_chunks(int M);

@@ -1208,7 +1208,7 @@ def test_linear_products_at_benchmark_size(dev, gemm_mode):
 @pytest.mark.parametrize("M,K0,H", [(300, 28, 200), (520, 52, 72), (16500, 28, 1000)])
 def test_pair_format_eval_chain(dev, M, K0, H):
     """Eval-mode units with their activations in the pair format (``btvae_linear_relu_affine_fwd_pairs``, csrc/pairs.h):
-    fp32 input -> pairs, pairs -> pairs, pairs -> fp32, each against fp64 on the values it was given; 128-row workgroups
+    fp32 input -> pairs, pairs -> pairs (plain and residual), pairs -> fp32, each against fp64 on the values it was given; 128-row workgroups
     and (M = 16,500) 256-row ones with a row group wholly past the matrix; pad columns of a pair-format row come back as
     zeros; whole-matrix encode / decode.  Tolerance: the two-piece product's (2e-6 relative + 2e-6 sqrt(K) of the operand
     scale) plus, for a pair-format output, 2^-22 of its block's maximum."""
@@ -1246,7 +1246,7 @@ def test_pair_format_eval_chain(dev, M, K0, H):
         nv.call("btvae_weight_planes_f16", P(Ws[0]), K0, H, K0, P(planes), 1, P(wmax))
         y1, s1 = pair_buffer()
         L.btvae_gemm_operand_maxima(P(xmax), P(wmax))
-        nv.call("btvae_linear_relu_affine_fwd_pairs", P(X0), K0, None, P(Ws[0]), P(planes), None, P(bs[0]), P(scs[0]), P(shs[0]),
+        nv.call("btvae_linear_relu_affine_fwd_pairs", P(X0), K0, None, P(Ws[0]), P(planes), None, P(bs[0]), P(scs[0]), P(shs[0]), 0,
                 P(y1), ld, P(s1), M, K0, H)
         torch.cuda.synchronize()
         assert torch.isfinite(s1).all() and (s1 > 0).all()
@@ -1262,19 +1262,28 @@ def test_pair_format_eval_chain(dev, M, K0, H):
         img = torch.empty(L.btvae_weight_image_pq_bytes(H, H, 0), dtype=torch.uint8, device=dev)
         nv.call("btvae_weight_image_pq", P(Ws[1]), H, H, H, 0, P(img), P(wmax2))
         y2, s2 = pair_buffer()
-        nv.call("btvae_linear_relu_affine_fwd_pairs", P(y1), ld, P(s1), None, P(img), P(wmax2), P(bs[1]), P(scs[1]), P(shs[1]),
+        nv.call("btvae_linear_relu_affine_fwd_pairs", P(y1), ld, P(s1), None, P(img), P(wmax2), P(bs[1]), P(scs[1]), P(shs[1]), 0,
                 P(y2), ld, P(s2), M, H, H)
         full2 = decode(y2, s2, ld)
         assert torch.equal(full2[:, H:], torch.zeros_like(full2[:, H:]))
         r2 = ref(x2, 1)
         close(full2[:, :H], r2, 2e-6, 2e-6 * math.sqrt(H) * float(x2.abs().max()) + 2.0 ** -22 * float(r2.abs().max()), "pairs -> pairs")
 
+        # the residual form: the pair-format input is added to the result (its block scale comes from a bound on the sum)
+        y2r, s2r = pair_buffer()
+        nv.call("btvae_linear_relu_affine_fwd_pairs", P(y1), ld, P(s1), None, P(img), P(wmax2), P(bs[1]), P(scs[1]), P(shs[1]), 1,
+                P(y2r), ld, P(s2r), M, H, H)
+        full2r = decode(y2r, s2r, ld)
+        assert torch.equal(full2r[:, H:], torch.zeros_like(full2r[:, H:]))
+        r2r = r2 + x2
+        close(full2r[:, :H], r2r, 2e-6, 2e-6 * math.sqrt(H) * float(x2.abs().max()) + 2.0 ** -20 * float(r2r.abs().max()), "pairs -> pairs, residual")
+
         # unit 3: pairs in, fp32 out
         wmax3 = slot(Ws[2])
         img3 = torch.empty(L.btvae_weight_image_pq_bytes(H, H, 0), dtype=torch.uint8, device=dev)
         nv.call("btvae_weight_image_pq", P(Ws[2]), H, H, H, 0, P(img3), P(wmax3))
         y3 = torch.full((M, ld), float("nan"), device=dev)
-        nv.call("btvae_linear_relu_affine_fwd_pairs", P(y2), ld, P(s2), None, P(img3), P(wmax3), P(bs[2]), P(scs[2]), P(shs[2]),
+        nv.call("btvae_linear_relu_affine_fwd_pairs", P(y2), ld, P(s2), None, P(img3), P(wmax3), P(bs[2]), P(scs[2]), P(shs[2]), 0,
                 P(y3), ld, None, M, H, H)
         x3 = full2[:, :H].double()
         close(y3[:, :H], ref(x3, 2), 2e-6, 2e-6 * math.sqrt(H) * float(x3.abs().max()), "pairs -> fp32")

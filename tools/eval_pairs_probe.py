@@ -56,13 +56,20 @@ def main():
 
     def f32_pairs():
         L.btvae_gemm_operand_maxima(P(xmax), P(wmax))
-        nv.call("btvae_linear_relu_affine_fwd_pairs", P(X), ld, None, P(W), P(planes), None, P(b), P(sc), P(sh), P(Y), ld, P(ys), M, K, N)
+        nv.call("btvae_linear_relu_affine_fwd_pairs", P(X), ld, None, P(W), P(planes), None, P(b), P(sc), P(sh), 0, P(Y), ld, P(ys), M, K, N)
 
     def pairs_f32():
-        nv.call("btvae_linear_relu_affine_fwd_pairs", P(Xp), ld, P(xs), None, P(img), P(wmax), P(b), P(sc), P(sh), P(Y), ld, None, M, K, N)
+        nv.call("btvae_linear_relu_affine_fwd_pairs", P(Xp), ld, P(xs), None, P(img), P(wmax), P(b), P(sc), P(sh), 0, P(Y), ld, None, M, K, N)
 
     def pairs_pairs():
-        nv.call("btvae_linear_relu_affine_fwd_pairs", P(Xp), ld, P(xs), None, P(img), P(wmax), P(b), P(sc), P(sh), P(Y), ld, P(ys), M, K, N)
+        nv.call("btvae_linear_relu_affine_fwd_pairs", P(Xp), ld, P(xs), None, P(img), P(wmax), P(b), P(sc), P(sh), 0, P(Y), ld, P(ys), M, K, N)
+
+    def f32_f32_res():
+        L.btvae_gemm_operand_maxima(P(xmax), P(wmax))
+        nv.call("btvae_linear_relu_affine_fwd_pw_ld", P(X), ld, P(W), P(planes), P(b), P(sc), P(sh), P(X), ld, P(Yref), ld, M, K, N)
+
+    def pairs_pairs_res():
+        nv.call("btvae_linear_relu_affine_fwd_pairs", P(Xp), ld, P(xs), None, P(img), P(wmax), P(b), P(sc), P(sh), 1, P(Y), ld, P(ys), M, K, N)
 
     f32_f32()
     pairs_f32()
@@ -70,7 +77,8 @@ def main():
     print("pairs -> fp32 against fp32 -> fp32: max abs difference", (Y[:, :N] - Yref[:, :N]).abs().max().item())
     fl = 2.0 * M * N * K
     for name, fn in (("fp32 -> fp32 (shipped 128-wide kernel)", f32_f32), ("fp32 -> pairs", f32_pairs), ("pairs -> fp32", pairs_f32), ("pairs -> pairs", pairs_pairs),
-                     ("fp32 -> fp32 again", f32_f32), ("pairs -> pairs again", pairs_pairs)):
+                     ("fp32 -> fp32 again", f32_f32), ("pairs -> pairs again", pairs_pairs),
+                     ("residual unit, fp32 -> fp32", f32_f32_res), ("residual unit, pairs -> pairs", pairs_pairs_res)):
         t = timeit(fn, reps)
         print(f"{name:42s} {t * 1e3:8.3f} ms {fl / t / 1e12:7.1f} TFLOP/s")
 
