@@ -25,7 +25,6 @@ LEGS = {
     "training_fwd:fp32_split2:65536": (r"gemm_split_mfma<0, 0, 2, true, 2, 1, 0>", 512 * 8, 256),
     "training_dgrad_gstats:fp32_split2:65536": (r"gemm_split_mfma<0, 1, 7, true, 2, 1, 0>", 512 * 8, 256),
     "training_dgrad_bnbwd:fp32_split2:65536": (r"gemm_split_mfma<0, 1, 6, true, 2, 1, 0>", 512 * 8, 256),
-    "scoring_fwd:fp32_split2:819200": (r"gemm_split_mfma<0, 0, 3, true, 2, 1, 0>", 6400 * 8, 256),
     "scoring_fwd_pairs:fp32_split2:819200": (r"gemm_pq256<3, 2, 0>", 3200 * 4, 512),
     "imputation_fwd:fp32_split2:25000": (r"gemm_split_mfma<0, 0, 3, true, 2, 1, 0>", 196 * 8, 256),
     "wide_hidden_layer:bf16:65536": (r"gemm_pq256<2, 2, 1>", 256 * 4, 512),
