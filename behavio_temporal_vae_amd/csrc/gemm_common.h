@@ -127,8 +127,9 @@ __device__ __forceinline__ void st4(float* q, const float4 v) { *reinterpret_cas
 // ROWS: how many of a thread's eight rows are read from the LDS image before their stores are issued on a row tile inside
 // the matrix: 8; fewer in the kernels whose 128 accumulator registers leave no room for eight rows in flight; 1 = every
 // tile takes the row-by-row path of the edge tiles (no second copy of the store code either).
-// PQOUT: the kernel may be asked for pair-format output (p.c_sc; EPI_RELU_AFFINE only).  ADDIN: 0 = an add-in is fp32 / bf16
-// or (with PQOUT) in the pair format, as the arguments say; 1 = the kernel is never given one; 2 = only pair-format ones.
+// PQOUT: the kernel may be asked for pair-format output (p.c_sc; EPI_RELU_AFFINE only).  ADDIN: 0 = an add-in is an fp32 or
+// bf16 matrix, as the arguments say; 1 = the kernel is never given one; 2 = an add-in is in the pair format (p.r_sc) and reaches
+// the rows through another 32 KiB of `lds` behind the 36 KiB named above.
 template <int EPI, bool AUX16 = false, int ROWS = 8, bool PQOUT = true, int ADDIN = 0>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[2][2], float* lds, int m0, int n0, int tile_m, int zz) {
     const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;

@@ -272,9 +272,10 @@ __device__ __forceinline__ int s_frag_off(int blk, int lane) {
 #define BTVAE_SPLIT_WG 2          // workgroups per CU the register budget is set for
 #endif
 #ifndef BTVAE_SPLIT_WG_TWO
-#define BTVAE_SPLIT_WG_TWO 3      // the same for the two-piece forward kernels (128 x 128 tile, 36 KiB of LDS per workgroup): a third
-                                  // workgroup per CU covers the other two's store phases (-3.5 % on the family; the dX and
-                                  // weight-gradient kernels gain nothing from it)
+#define BTVAE_SPLIT_WG_TWO 3      // the same for the two-piece forward and dX kernels (128 x 128 tile, 36 KiB of LDS per workgroup): a third
+                                  // workgroup per CU covers the other two's store phases (-3.5 % on the forward family, -2.7 % on
+                                  // the dX one; not the dX kernel that applies the BatchNorm backward, whose epilogue would spill
+                                  // 16 registers at that budget, nor the weight gradients' 128 x 256 tile)
 #endif
 
 template <bool PRE> struct BStageOf { typedef SStage type; };
@@ -290,7 +291,7 @@ template <> struct AStageOf<1> { typedef QStage type; };
 // no split arithmetic for it, and its scale changes every 128 reduction steps -- the accumulators are carried in units of
 // the current block's scale and multiplied by the ratio of two scales (powers of two: exact) at each block boundary.
 template <int AL, int BL, int EPI, bool BPRE = false, int NPL = 3, int NB = 1, int AF = 0>
-__global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && BL == LAY_K) ? BTVAE_SPLIT_WG_TWO : BTVAE_SPLIT_WG) void gemm_split_mfma(const GemmArgs p) {
+__global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && EPI != EPI_BNBWD) ? BTVAE_SPLIT_WG_TWO : BTVAE_SPLIT_WG) void gemm_split_mfma(const GemmArgs p) {
     static_assert(AF == 0 || (AL == LAY_K && NPL == 2), "pair-format A: k-contiguous, two pieces");
     typedef typename BStageOf<BPRE>::type BStage;
     typedef typename AStageOf<AF>::type AStage;
