@@ -190,6 +190,18 @@ def test_gipuzkoa_k1000_scoring_vs_oracle(dev):
     assert rel_err(rlls.cpu().numpy(), rl64.numpy()) < 1e-4
     assert rel_err(ll.cpu().numpy(), ll64.numpy()) < 1e-4
     assert rel_err(kl.cpu().numpy(), kl64.numpy()) < 1e-4
+    # the same against the oracle with the hidden activations kept in the pair format (what the benchmark's 819,200-row
+    # chunks do; these 1,600-row chunks are below the row count from which the engine switches on its own)
+    from behavio_temporal_vae_amd import engine as E
+    keep = E.EVAL_PAIRS_MIN_ROWS
+    try:
+        E.EVAL_PAIRS_MIN_ROWS = 0
+        ll, rlls, kl = testing_lib.iw_loglikelihood_device(m, x.to(dev), c.to(dev), K, mc_sample_batch_size=25, eps=eps.to(dev), return_rlls=True)
+    finally:
+        E.EVAL_PAIRS_MIN_ROWS = keep
+    assert rel_err(rlls.cpu().numpy(), rl64.numpy()) < 1e-4
+    assert rel_err(ll.cpu().numpy(), ll64.numpy()) < 1e-4
+    assert rel_err(kl.cpu().numpy(), kl64.numpy()) < 1e-4
 
 
 def test_pseudo_gibbs_vs_reference(dev):
