@@ -578,6 +578,11 @@ std::atomic<int> g_precision{0};
 
 // `reduced_ok`: this product may run with bf16-ROUNDED operands when that mode is selected (Linear fwd/dgrad/wgrad);
 // the covariance products of the likelihood never do.  The split mode is fp32-accurate and applies to every product.  On return a.kchunk holds the split length used.
+#ifdef BTVAE_EXPERIMENTS
+// experiment: the B operand of the next weight-gradient product from this thread is in the pair format (its block scales)
+thread_local const float* t_b_pairs = nullptr;
+#endif
+
 template <int AL, int BL, int EPI>
 int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduced_ok = false) {
     a.amax_a = t_amax_a; a.amax_b = t_amax_b;
@@ -630,7 +635,11 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     // fp32-accurate on the bf16 pipe: every product of the split modes, and in the bf16 mode the products that must not
     // round their operands (the likelihood's covariance products)
     const bool split = (prec >= 2 || (prec == 1 && !reduced_ok)) && a.a_vec && a.b_vec;
-    const bool two = split && prec == 3 && has_twopiece<AL, BL, EPI>() && a.amax_a && a.amax_b;
+#ifdef BTVAE_EXPERIMENTS
+    if constexpr (AL == LAY_M && BL == LAY_M && EPI == EPI_PLAIN) { a.b_sc = t_b_pairs; a.b_scn = (a.N + 127) / 128; }
+    t_b_pairs = nullptr;
+#endif
+    const bool two = split && prec == 3 && has_twopiece<AL, BL, EPI>() && a.amax_a && (a.amax_b || a.b_sc);
     if ((prec == 3 && !two) || prec == 1) a.Bp = nullptr;        // planes made in these modes hold fp16 pieces / bf16 stage images
     // 128 x 256 block tile: the weight gradients, whose two operands are both split in the kernel (+5-10 %; the products
     // with a pre-split weight gain nothing from it and short reductions lose to its longer epilogue)
@@ -662,6 +671,15 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
             }
         }
         if constexpr (has_twopiece<AL, BL, EPI>()) {
+#ifdef BTVAE_EXPERIMENTS
+            if constexpr (AL == LAY_M && BL == LAY_M && EPI == EPI_PLAIN) {
+                if (!pre && two && a.b_sc) {
+                    pre = true;
+                    if (wide) hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI, false, 2, 2, 2>), grid, dim3(256), 0, s, a);
+                    else      hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI, false, 2, 1, 2>), grid, dim3(256), 0, s, a);
+                }
+            }
+#endif
             if constexpr (AL == LAY_M) {
                 if (!pre && wide) { pre = true; hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI, false, 2, 2>), grid, dim3(256), 0, s, a); }
             }
@@ -1092,6 +1110,9 @@ BTVAE_API int btvae_linear_relu_stats_fwd_bh256(const void* X, int ldx, const vo
     ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N));
     return launch_bh256<EPI_RELU_STATS>(a, groups, (hipStream_t)stream, "linear_relu_stats_fwd_bh256");
 }
+
+// experiment: the next btvae_linear_wgrad from this thread reads X in the pair format (sc = its block scales; ldx in floats)
+BTVAE_API int btvae_next_wgrad_pairs(const float* sc) { t_b_pairs = sc; return 0; }
 
 BTVAE_API int btvae_linear_relu_stats_fwd_pq256(const void* Xp, int ldx, const float* xsc, const void* Wimage, const float* wmax, const float* b,
                                                 float* Y, float* stat_partials, int M, int K, int N, int groups, void* stream) {

@@ -46,6 +46,8 @@ struct GemmArgs {
     float* amax_out;            // null, or where max |stored C| is folded in (EPI_RELU_STATS, EPI_RELU_AFFINE, EPI_BNBWD)
     // A operand stored as fp16 pairs with one power-of-two scale per 128 x 128 block (pairs.h): a_sc[row tile][a_scn]
     const float* a_sc; int a_scn;
+    // B operand of a weight gradient (m-contiguous: rows = reduction steps) stored in the pair format: b_sc[row block][b_scn]
+    const float* b_sc; int b_scn;
     // EPI_RELU_AFFINE: non-null = the output is written in that format, one block per 128 x 128 tile, its scales to
     // c_sc[row tile][c_scn] (ldc counts floats: a pair-format row has the bytes of the fp32 row it replaces); no add-in then
     float* c_sc; int c_scn;

@@ -222,6 +222,36 @@ __device__ __forceinline__ void q_r2s(__bf16* S, int tid, const QStage& st) {
     }
 }
 
+// Pair-format operand read along its rows (m-contiguous: the B operand of a weight gradient, rows = reduction steps): thread
+// (mq = tid & 31, kp = tid >> 5) takes, for k = 2 kp + j, the run of four high pieces of columns 4 mq .. and the run of four
+// low pieces 32 bytes further -- the 8-byte stores of s_r2s2 without the split.  v[4j .. 4j+3] = (P0, P1, Q0, Q1) as bits.
+template <bool FULL>
+__device__ __forceinline__ void qm_g2r(const unsigned short* __restrict__ P, int ldh, int col0, int ncols, int k0, int kend, int tid, SStage& st) {
+    const int mq = tid & 31, kp = tid >> 5;
+    const int gm = col0 + (mq << 2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int gk = k0 + kp * 2 + j;
+        nat_u2 hi = {0u, 0u}, lo = {0u, 0u};
+        if (FULL || (gk < kend && gm + 3 < ncols)) {
+            const unsigned short* src = P + (size_t)gk * ldh + btvae_pairs::pq_col(FULL ? min(gm, ncols - 4) : gm);
+            hi = *reinterpret_cast<const nat_u2*>(src);
+            lo = *reinterpret_cast<const nat_u2*>(src + 16);
+        }
+        st.v[4 * j] = __uint_as_float(hi.x); st.v[4 * j + 1] = __uint_as_float(hi.y);
+        st.v[4 * j + 2] = __uint_as_float(lo.x); st.v[4 * j + 3] = __uint_as_float(lo.y);
+    }
+}
+__device__ __forceinline__ void qm_r2s(__bf16* S, int tid, const SStage& st) {
+    const int mq = tid & 31, kp = tid >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        __bf16* dst = S + (kp * 2 + j) * MPITCH + (mq << 2);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(__float_as_uint(st.v[4 * j]), __float_as_uint(st.v[4 * j + 1]));
+        *reinterpret_cast<uint2*>(dst + MPLANE) = make_uint2(__float_as_uint(st.v[4 * j + 2]), __float_as_uint(st.v[4 * j + 3]));
+    }
+}
+
 template <int LAY, int NPL = 3>
 __device__ __forceinline__ void p_r2s(__bf16* S, int tid, const PStage& st) {
     constexpr int PL = LAY == LAY_K ? SPLANE : MPLANE;
@@ -290,12 +320,15 @@ template <> struct AStageOf<1> { typedef QStage type; };
 // AF = 1: the A operand is stored in the pair format (p.A reinterpreted, p.a_sc its block scales; k-contiguous, NPL = 2):
 // no split arithmetic for it, and its scale changes every 128 reduction steps -- the accumulators are carried in units of
 // the current block's scale and multiplied by the ratio of two scales (powers of two: exact) at each block boundary.
+// AF = 2: the same for the B operand of a weight gradient (p.B reinterpreted, p.b_sc; m-contiguous: the reduction runs
+// down the rows, so each 128-column sub-tile follows its own column of block scales).
 template <int AL, int BL, int EPI, bool BPRE = false, int NPL = 3, int NB = 1, int AF = 0>
 __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && EPI != EPI_BNBWD) ? BTVAE_SPLIT_WG_TWO : BTVAE_SPLIT_WG) void gemm_split_mfma(const GemmArgs p) {
-    static_assert(AF == 0 || (AL == LAY_K && NPL == 2), "pair-format A: k-contiguous, two pieces");
+    static_assert(AF == 0 || (AF == 1 && AL == LAY_K && NPL == 2) || (AF == 2 && AL == LAY_M && BL == LAY_M && NPL == 2 && !BPRE),
+                  "pair-format A: k-contiguous, two pieces; pair-format B: the weight gradient's m-contiguous operand, two pieces");
     typedef typename BStageOf<BPRE>::type BStage;
-    typedef typename AStageOf<AF>::type AStage;
-    constexpr int APAD = AF ? QPAD : 0;
+    typedef typename AStageOf<AF == 1 ? 1 : 0>::type AStage;
+    constexpr int APAD = AF == 1 ? QPAD : 0;
     typedef _Float16 sf16x8 __attribute__((ext_vector_type(8)));
     constexpr int PD = NB == 2 ? BTVAE_SPLIT_PD_WIDE : BTVAE_SPLIT_PD;
     constexpr int PLA = plane_elems<AL>(), PLB = plane_elems<BL>();
@@ -305,12 +338,12 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && EPI != 
     constexpr int LDS_ELEMS = 2 * BUF > EPI_BF16 ? 2 * BUF : EPI_BF16;
     __shared__ __attribute__((aligned(16))) __bf16 smem_raw[LDS_ELEMS];
     float sc_a = 1.f, sc_b = 1.f;
-    if (NPL == 2) { sc_a = AF ? 1.f : scale_for(*p.amax_a); sc_b = scale_for(*p.amax_b); }
+    if (NPL == 2) { sc_a = AF == 1 ? 1.f : scale_for(*p.amax_a); sc_b = AF == 2 ? 1.f : scale_for(*p.amax_b); }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (NPL == 2 && p.guard && blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) {
         // an operand with a region far below its tensor's maximum: say so (the host routes this product to the
         // three-piece kernel from then on)
-        if ((!AF && slot_range_exceeded(p.amax_a, p.guard_log2)) || slot_range_exceeded(p.amax_b, p.guard_log2)) p.guard[0] = 1;
+        if ((AF != 1 && slot_range_exceeded(p.amax_a, p.guard_log2)) || (AF != 2 && slot_range_exceeded(p.amax_b, p.guard_log2))) p.guard[0] = 1;
     }
     const int wr = wid >> 1, wc = wid & 1;
 
@@ -337,6 +370,10 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && EPI != 
 #pragma unroll
         for (int h = 0; h < NB; ++h) {
             if constexpr (BPRE) p_g2r<NPL>(p, n0 + h * BN, k0, tid, b[h]);
+            else if constexpr (AF == 2) {
+                if (full) qm_g2r<true>(reinterpret_cast<const unsigned short*>(p.B), 2 * p.ldb, n0 + h * BN, p.N, k0, kend, tid, b[h]);
+                else qm_g2r<false>(reinterpret_cast<const unsigned short*>(p.B), 2 * p.ldb, n0 + h * BN, p.N, k0, kend, tid, b[h]);
+            }
             else if (full) s_g2r<BL, true>(p.B, p.ldb, n0 + h * BN, p.N, k0, kend, tid, b[h]);
             else s_g2r<BL, false>(p.B, p.ldb, n0 + h * BN, p.N, k0, kend, tid, b[h]);
         }
@@ -345,6 +382,7 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && EPI != 
 #pragma unroll
         for (int h = 0; h < NB; ++h) {
             if constexpr (BPRE) p_r2s<BL, NPL>(S + h * BSUB, tid, b[h]);
+            else if constexpr (AF == 2) qm_r2s(S + h * BSUB, tid, b[h]);
             else if constexpr (NPL == 2) s_r2s2<BL>(S + h * BSUB, tid, b[h], sc_b);
             else s_r2s<BL>(S + h * BSUB, tid, b[h]);
         }
@@ -372,9 +410,36 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && EPI != 
     };
     // pair-format A: block scales of this row tile; after the last k-tile of a 128-k block the accumulators move to the
     // next block's units
-    const float* asc = AF ? p.a_sc + (size_t)tile_m * p.a_scn : nullptr;
+    const float* asc = AF == 1 ? p.a_sc + (size_t)tile_m * p.a_scn : nullptr;
     if constexpr (AF == 1) sc_a = asc[kbeg >> 7];
+    // pair-format B (weight gradient): its block scales run along the reduction, one column of blocks per 128-column sub-tile
+    float scb[NB];
+#pragma unroll
+    for (int h = 0; h < NB; ++h) scb[h] = 1.f;
+    if constexpr (AF == 2) {
+#pragma unroll
+        for (int h = 0; h < NB; ++h)
+            if (n0 + h * BN < p.N && kbeg < kend) scb[h] = p.b_sc[(size_t)(kbeg >> 7) * p.b_scn + ((n0 + h * BN) >> 7)];
+    }
     auto rescale = [&](int t) {
+        if constexpr (AF == 2) {
+            const int k1 = kbeg + (t + 1) * SBK;
+            if ((k1 & 127) == 0 && k1 < kend) {
+#pragma unroll
+                for (int h = 0; h < NB; ++h) {
+                    if (n0 + h * BN >= p.N) continue;
+                    const float nx = p.b_sc[(size_t)(k1 >> 7) * p.b_scn + ((n0 + h * BN) >> 7)];
+                    const float r = nx * btvae_pairs::pq_inv(scb[h]);
+                    scb[h] = nx;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) acc[h][i][j][e] *= r;
+                }
+            }
+        }
         if constexpr (AF == 1) {
             const int k1 = kbeg + (t + 1) * SBK;
             if ((k1 & 127) == 0 && k1 < kend) {
@@ -558,7 +623,7 @@ __global__ __launch_bounds__(256, (NPL == 2 && NB == 1 && AL == LAY_K && EPI != 
             if (worst >= 0x7f800000u) p.guard[1] = 1;
         }
         if (NPL == 2) {
-            const float ia = AF ? btvae_pairs::pq_inv(sc_a) : 1.f / sc_a, ib = 1.f / sc_b;   // powers of two: exact, applied one after the other to stay in range
+            const float ia = AF == 1 ? btvae_pairs::pq_inv(sc_a) : 1.f / sc_a, ib = AF == 2 ? btvae_pairs::pq_inv(scb[h]) : 1.f / sc_b;   // powers of two: exact, applied one after the other to stay in range
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
