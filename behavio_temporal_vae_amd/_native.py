@@ -40,6 +40,9 @@ _SIGS = {
     "btvae_guard_check": [P, P, I, P],
     "btvae_weight_image_bf16": [P, I, I, I, I, P, P],
     "btvae_pairs_encode": [P, I, P, I, P, I, I, P],
+    "btvae_linear_relu_stats_fwd_pairs": [P, I, P, P, P, P, P, I, P, I, I, I, P],
+    "btvae_linear_wgrad_pairs": [P, P, I, P, P, P, LL, I, I, I, I, P],
+    "btvae_bn_apply_fwd_pairs": [P, I, P, P, P, P, P, I, P, P, I, P, I, I, P],
     "btvae_pairs_decode": [P, I, P, P, I, I, I, P],
     "btvae_weight_image_pq": [P, I, I, I, I, P, P, P],
     "btvae_linear_relu_affine_fwd_pairs": [P, I, P, P, P, P, P, P, P, I, P, I, P, I, I, I, P],

@@ -4,6 +4,7 @@
 // Cross-workgroup reductions go through small partial arrays finished in fp64 by one thread per
 // column, so results are deterministic (no float atomics).
 #include "common.h"
+#include "pairs.h"
 #include <algorithm>
 
 namespace {
@@ -189,6 +190,62 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
         }
     }
     wave_amax_commit(vmax, amax_out);          // every lane is here (lanes past the last column hold 0)
+}
+
+// The same pass writing its output in the pair format (pairs.h): one workgroup per 128 x 128 block, which is what a block
+// scale spans -- thread t holds columns 4 (t & 31) .. + 3 of rows (t >> 5) + 8 j, the block's largest |value| decides the
+// scale before anything is written.  Y is fp32 (pitch ldy); the add-in R (the unit's input, pitch ldr) is absent (RF 0), fp32
+// (RF 1) or itself in the pair format with block scales r_sc (RF 2).  No dropout flags.
+template <int RF>
+__global__ __launch_bounds__(256) void bn_apply_fwd_pairs_kernel(const float* __restrict__ Y, int ldy, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ R, int ldr,
+                                                                 const float* __restrict__ r_sc, unsigned short* __restrict__ Out, int ldo,
+                                                                 float* __restrict__ out_sc, int M, int N) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, r0 = blockIdx.y * 128 + (tid >> 5), c = blockIdx.x * 128 + ((tid & 31) << 2);
+    const bool ok = c < N;                            // N % 4 == 0: a 4-column group is in or out as a whole
+    float sc[4], sh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (mean && ok) {
+            const float s = invstd[c + e] * gamma[c + e];
+            sc[e] = s; sh[e] = beta[c + e] - mean[c + e] * s;
+        } else { sc[e] = 1.f; sh[e] = 0.f; }
+    }
+    float rinv = 1.f;
+    if (RF == 2) rinv = btvae_pairs::pq_inv(r_sc[(size_t)blockIdx.y * gridDim.x + blockIdx.x]);
+    float4 v[16];
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = r0 + 8 * j;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < M && ok) {
+            const nat_f4 y = *reinterpret_cast<const nat_f4*>(Y + (size_t)r * ldy + c);
+            v[j] = make_float4(y.x * sc[0] + sh[0], y.y * sc[1] + sh[1], y.z * sc[2] + sh[2], y.w * sc[3] + sh[3]);
+            if (RF == 1) {
+                const nat_f4 q = *reinterpret_cast<const nat_f4*>(R + (size_t)r * ldr + c);
+                v[j].x += q.x; v[j].y += q.y; v[j].z += q.z; v[j].w += q.w;
+            } else if (RF == 2) {
+                const float4 q = btvae_pairs::pq_load4(reinterpret_cast<const unsigned short*>(R) + (size_t)r * (2 * ldr), c, rinv);
+                v[j].x += q.x; v[j].y += q.y; v[j].z += q.z; v[j].w += q.w;
+            }
+        }
+        m = amax4(m, v[j]);
+    }
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    const float s = btvae_pairs::pq_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (tid == 0) out_sc[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+    if (c < ldo) {                                    // columns between N and the pitch: zeros (v is zero there)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int r = r0 + 8 * j;
+            if (r < M) btvae_pairs::pq_store4(Out + (size_t)r * (2 * ldo), c, v[j], s);
+        }
+    }
 }
 
 // ---- backward pass 1: per column s1 = sum g, s2 = sum g * xhat ----
@@ -529,6 +586,28 @@ BTVAE_API int btvae_bn_apply_fwd(const float* Y, const float* mean, const float*
     else
         hipLaunchKernelGGL((bn_apply_fwd_kernel<1>), dim3((N + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, Y, mean, invstd, gamma, beta, R, keep, keep_scale, Out, M, N, ld, rpc, amax_out);
     return check_launch("bn_apply_fwd");
+}
+
+// btvae_bn_apply_fwd without dropout, writing Out in the pair format (out_sc receives its block scales; ldo % 16 == 0,
+// N % 4 == 0).  Y is fp32 with pitch ldy; R (may be null) has pitch ldr and is fp32 (r_sc null) or in the pair format.
+BTVAE_API int btvae_bn_apply_fwd_pairs(const float* Y, int ldy, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                       const void* R, int ldr, const float* r_sc, void* Out, int ldo, float* out_sc, int M, int N,
+                                       void* stream) {
+    BTVAE_REQUIRE(Y && Out && out_sc && M > 0 && N > 0, "bn_apply_fwd_pairs: null pointer or empty");
+    BTVAE_REQUIRE(mean ? (invstd && gamma && beta) : (!invstd && !gamma && !beta), "bn_apply_fwd_pairs: pass all four BatchNorm vectors or none");
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    BTVAE_REQUIRE(N % 4 == 0 && ldy % 4 == 0 && ldy >= N && ldo % 16 == 0 && ldo >= N && al(Y) && al(Out) && al(mean) && al(invstd) && al(gamma) && al(beta),
+                  "bn_apply_fwd_pairs: needs N %% 4 == 0, 16-byte aligned tensors, ldy %% 4 == 0 and ldo %% 16 == 0 (N %d, ldy %d, ldo %d)", N, ldy, ldo);
+    BTVAE_REQUIRE(!R || (al(R) && ldr >= N && ldr % (r_sc ? 16 : 4) == 0), "bn_apply_fwd_pairs: add-in pitch %d", ldr);
+    ProfScope ps(PK_BN, (hipStream_t)stream, 0, 4.0 * M * N * (R ? 3 : 2));
+    const dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
+    unsigned short* out = reinterpret_cast<unsigned short*>(Out);
+    const float* r = reinterpret_cast<const float*>(R);
+    hipStream_t s = (hipStream_t)stream;
+    if (!R)        hipLaunchKernelGGL((bn_apply_fwd_pairs_kernel<0>), grid, dim3(256), 0, s, Y, ldy, mean, invstd, gamma, beta, r, ldr, r_sc, out, ldo, out_sc, M, N);
+    else if (!r_sc) hipLaunchKernelGGL((bn_apply_fwd_pairs_kernel<1>), grid, dim3(256), 0, s, Y, ldy, mean, invstd, gamma, beta, r, ldr, r_sc, out, ldo, out_sc, M, N);
+    else            hipLaunchKernelGGL((bn_apply_fwd_pairs_kernel<2>), grid, dim3(256), 0, s, Y, ldy, mean, invstd, gamma, beta, r, ldr, r_sc, out, ldo, out_sc, M, N);
+    return check_launch("bn_apply_fwd_pairs");
 }
 
 // BatchNorm+ReLU backward.  G = dL/d(BN output), Y = post-ReLU pre-BN activations saved by the forward.

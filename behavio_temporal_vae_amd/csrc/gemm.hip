@@ -578,11 +578,6 @@ std::atomic<int> g_precision{0};
 
 // `reduced_ok`: this product may run with bf16-ROUNDED operands when that mode is selected (Linear fwd/dgrad/wgrad);
 // the covariance products of the likelihood never do.  The split mode is fp32-accurate and applies to every product.  On return a.kchunk holds the split length used.
-#ifdef BTVAE_EXPERIMENTS
-// experiment: the B operand of the next weight-gradient product from this thread is in the pair format (its block scales)
-thread_local const float* t_b_pairs = nullptr;
-#endif
-
 template <int AL, int BL, int EPI>
 int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduced_ok = false) {
     a.amax_a = t_amax_a; a.amax_b = t_amax_b;
@@ -635,10 +630,8 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     // fp32-accurate on the bf16 pipe: every product of the split modes, and in the bf16 mode the products that must not
     // round their operands (the likelihood's covariance products)
     const bool split = (prec >= 2 || (prec == 1 && !reduced_ok)) && a.a_vec && a.b_vec;
-#ifdef BTVAE_EXPERIMENTS
-    if constexpr (AL == LAY_M && BL == LAY_M && EPI == EPI_PLAIN) { a.b_sc = t_b_pairs; a.b_scn = (a.N + 127) / 128; }
-    t_b_pairs = nullptr;
-#endif
+    BTVAE_REQUIRE(!a.b_sc || (AL == LAY_M && BL == LAY_M && EPI == EPI_PLAIN && prec == 3 && a.amax_a && a.b_vec && a.ldb % 16 == 0),
+                  "%s: a pair-format B operand belongs to the weight gradients of the two-piece mode (maximum of the other operand given, pitch a multiple of 16)", what);
     const bool two = split && prec == 3 && has_twopiece<AL, BL, EPI>() && a.amax_a && (a.amax_b || a.b_sc);
     if ((prec == 3 && !two) || prec == 1) a.Bp = nullptr;        // planes made in these modes hold fp16 pieces / bf16 stage images
     // 128 x 256 block tile: the weight gradients, whose two operands are both split in the kernel (+5-10 %; the products
@@ -671,15 +664,13 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
             }
         }
         if constexpr (has_twopiece<AL, BL, EPI>()) {
-#ifdef BTVAE_EXPERIMENTS
             if constexpr (AL == LAY_M && BL == LAY_M && EPI == EPI_PLAIN) {
-                if (!pre && two && a.b_sc) {
+                if (!pre && two && a.b_sc) {            // B operand stored in the pair format: its pieces as they are
                     pre = true;
                     if (wide) hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI, false, 2, 2, 2>), grid, dim3(256), 0, s, a);
                     else      hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI, false, 2, 1, 2>), grid, dim3(256), 0, s, a);
                 }
             }
-#endif
             if constexpr (AL == LAY_M) {
                 if (!pre && wide) { pre = true; hipLaunchKernelGGL((gemm_split_mfma<AL, BL, EPI, false, 2, 2>), grid, dim3(256), 0, s, a); }
             }
@@ -1111,9 +1102,6 @@ BTVAE_API int btvae_linear_relu_stats_fwd_bh256(const void* X, int ldx, const vo
     return launch_bh256<EPI_RELU_STATS>(a, groups, (hipStream_t)stream, "linear_relu_stats_fwd_bh256");
 }
 
-// experiment: the next btvae_linear_wgrad from this thread reads X in the pair format (sc = its block scales; ldx in floats)
-BTVAE_API int btvae_next_wgrad_pairs(const float* sc) { t_b_pairs = sc; return 0; }
-
 BTVAE_API int btvae_linear_relu_stats_fwd_pq256(const void* Xp, int ldx, const float* xsc, const void* Wimage, const float* wmax, const float* b,
                                                 float* Y, float* stat_partials, int M, int K, int N, int groups, void* stream) {
     const RowPitches rp = take_row_pitches();
@@ -1141,6 +1129,20 @@ BTVAE_API int btvae_linear_relu_affine_fwd_pw_ld(const float* X, int ldx, const 
     a.bias = b; a.scale = scale; a.shift = shift; a.R = R; a.ldr = ldr; set_planes(a, Wplanes, N, K, false);
     ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     return launch<LAY_K, LAY_K, EPI_RELU_AFFINE>(a, 1, (hipStream_t)stream, "linear_relu_affine_fwd", true);
+}
+
+// Y = relu(X W^T + b) with per-tile column statistics (btvae_linear_relu_stats_fwd_pw) for an X in the pair format:
+// Wimage = btvae_weight_image_pq images of W made with the maximum *wmax; Y is an fp32 matrix with pitch ldy.
+BTVAE_API int btvae_linear_relu_stats_fwd_pairs(const void* Xp, int ldx, const float* x_sc, const void* Wimage, const float* wmax, const float* b,
+                                                float* Y, int ldy, float* stat_partials, int M, int K, int N, void* stream) {
+    BTVAE_REQUIRE(b && stat_partials && x_sc && Wimage && wmax, "linear_relu_stats_fwd_pairs: null pointer");
+    BTVAE_REQUIRE(g_precision.load(std::memory_order_relaxed) == 3, "linear_relu_stats_fwd_pairs: pair-format operands belong to the two-piece mode");
+    BTVAE_REQUIRE(ldy >= N, "linear_relu_stats_fwd_pairs: row pitch %d below N = %d", ldy, N);
+    GemmArgs a{}; a.A = (const float*)Xp; a.lda = ldx; a.a_sc = x_sc; a.C = Y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
+    a.bias = b; a.stats = stat_partials; a.Bp = (const unsigned short*)Wimage; a.amax_b = wmax;
+    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    const int wide_tiles = ((M + 255) / 256) * ((N + QN - 1) / QN);
+    return launch_pq256<EPI_RELU_STATS>(a, wide_tiles >= 256 ? 2 : 1, (hipStream_t)stream, "linear_relu_stats_fwd_pairs");
 }
 
 // The same unit with its activations in the pair format (eval-mode chains of the two-piece mode); `residual`: Out += X
@@ -1305,8 +1307,10 @@ BTVAE_API int btvae_linear_dgrad_gstats(const float* dY, const float* W, const f
 static int matmul_tn_impl(const float* A, int lda, const float* B, int ldb, float* C, float* ws, long long ws_floats,
                           int M, int N, int K, int accumulate, int prof_kind, hipStream_t s,
                           const float* scale, const float* shift, const float* rowv,
-                          const float* W = nullptr, float* col_wp = nullptr, float* col_wb = nullptr, int cols_accumulate = 0) {
+                          const float* W = nullptr, float* col_wp = nullptr, float* col_wb = nullptr, int cols_accumulate = 0,
+                          const float* b_sc = nullptr) {
     GemmArgs a{}; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.ldc = N; a.M = M; a.N = N; a.K = K;
+    a.b_sc = b_sc; a.b_scn = (N + 127) / 128;            // B in the pair format (a weight gradient's activation operand)
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const size_t out_elems = (size_t)M * N;
     int splits = pick_splits(tiles, K, ws ? (size_t)ws_floats : 0, out_elems);
@@ -1355,6 +1359,18 @@ BTVAE_API int btvae_linear_wgrad(const float* dY, const float* X, int ldx, float
     int lddy;
     BTVAE_REQUIRE(pitch_of(rp.n, N, lddy), "linear_wgrad: row pitch %d below N = %d", rp.n, N);
     return btvae_matmul_tn(dY, lddy, X, ldx, dW, ws, ws_floats, N, K, M, accumulate, PK_GEMM_WGRAD, stream);
+}
+
+// The same with X in the pair format (csrc/pairs.h; x_sc = its block scales, ldx in floats): two-piece mode, the maximum of dY
+// handed over through btvae_gemm_operand_maxima(dY's slot, NULL).
+BTVAE_API int btvae_linear_wgrad_pairs(const float* dY, const void* Xp, int ldx, const float* x_sc, float* dW, float* ws, long long ws_floats,
+                                       int M, int N, int K, int accumulate, void* stream) {
+    const RowPitches rp = take_row_pitches();
+    int lddy;
+    BTVAE_REQUIRE(pitch_of(rp.n, N, lddy), "linear_wgrad_pairs: row pitch %d below N = %d", rp.n, N);
+    BTVAE_REQUIRE(x_sc, "linear_wgrad_pairs: null block scales");
+    return matmul_tn_impl(dY, lddy, (const float*)Xp, ldx, dW, ws, ws_floats, N, K, M, accumulate, PK_GEMM_WGRAD, (hipStream_t)stream,
+                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, x_sc);
 }
 
 // Weight gradient of a Linear whose input is X = Y * scale + shift (column-wise, never materialised):

@@ -346,10 +346,11 @@ class _Guard:
 GUARD = _Guard()
 
 
-def _operand_maxima(a: Optional[torch.Tensor], b: Optional[torch.Tensor], key=None):
+def _operand_maxima(a: Optional[torch.Tensor], b: Optional[torch.Tensor], key=None, b_pairs: bool = False):
     """Hand the next product its operands' maxima (both or nothing) and its guard site; a site whose range flag is up
-    gets neither and runs on three exact pieces."""
-    if a is None or b is None:
+    gets neither and runs on three exact pieces.  ``b_pairs``: the B operand is in the pair format and has no maximum of its
+    own (a weight gradient on a ``Pairs`` activation): only A's is handed over, and the guard watches A alone."""
+    if a is None or (b is None and not b_pairs):
         return
     L = nv.lib()
     if key is None or not GUARD.enabled:
@@ -358,9 +359,9 @@ def _operand_maxima(a: Optional[torch.Tensor], b: Optional[torch.Tensor], key=No
     s = GUARD.site(key)
     f = GUARD.flags()
     if GUARD.strict and not f[2 * s] and not torch.cuda.is_current_stream_capturing():
-        nv.call("btvae_guard_check", P(a), P(b), s)
+        nv.call("btvae_guard_check", P(a), P(b if b is not None else a), s)
         torch.cuda.current_stream().synchronize()
-    if f[2 * s]:
+    if f[2 * s] and not b_pairs:                  # (a pair-format operand has no three-piece form to fall back to)
         GUARD.fallbacks += 1
         return
     L.btvae_gemm_operand_maxima(P(a), P(b))
@@ -521,6 +522,13 @@ EVAL_PAIRS = os.environ.get("BTVAE_EVAL_PAIRS", "1") != "0"
 EVAL_PAIRS_MIN_ROWS = int(os.environ.get("BTVAE_EVAL_PAIRS_MIN_ROWS", "65536"))
 
 
+# Training: the output of a BatchNorm-apply pass (a unit whose result has to exist in memory: it feeds a residual unit or is one)
+# in the pair format when every reader is a BatchNorm unit's Linear -- that Linear's forward product and its weight gradient
+# take the pieces as they are, a residual reader adds them.  From the same row count on as the eval-mode chains.
+TRAIN_PAIRS = os.environ.get("BTVAE_TRAIN_PAIRS", "0") == "1"
+TRAIN_PAIRS_MIN_ROWS = int(os.environ.get("BTVAE_TRAIN_PAIRS_MIN_ROWS", "65536"))
+
+
 class Pairs:
     """A hidden activation in the pair format (csrc/pairs.h): ``data`` is an [M, N] fp32-typed view with a pitch that is a
     multiple of 32 floats whose bytes hold, per row and 16 columns, the 16 high and the 16 low fp16 pieces of the values;
@@ -551,6 +559,12 @@ def _eval_pairs_ok(M: int, N: int) -> bool:
     rows, rows on a pitch that is a multiple of 16 floats, 16-byte column groups."""
     pitch = -(-N // ROW_LINE_FLOATS) * ROW_LINE_FLOATS
     return (EVAL_PAIRS and M >= EVAL_PAIRS_MIN_ROWS and _split_mode() == 2 and PRESPLIT_WEIGHTS and N % 4 == 0
+            and (PITCHED_ROWS or pitch == N))
+
+
+def _train_pairs_ok(M: int, N: int) -> bool:
+    pitch = -(-N // ROW_LINE_FLOATS) * ROW_LINE_FLOATS
+    return (TRAIN_PAIRS and M >= TRAIN_PAIRS_MIN_ROWS and _split_mode() == 2 and PRESPLIT_WEIGHTS and N % 4 == 0
             and (PITCHED_ROWS or pitch == N))
 
 
@@ -614,11 +628,18 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         tiles = (M + 127) // 128
         y = _rows_on_lines(M, N, dev)
         part = WS.get("bnpart", tiles * 2 * N, dev)
-        _operand_maxima(_amax(x), _planes_amax(wp, W), (id(u.lin.weight), "fwd"))
-        _track_output(y)
-        _pitches(n=y)
-        _bf16(a=x, out=y)
-        nv.call("btvae_linear_relu_stats_fwd_pw", PR(x), x.stride(0), P(W), P(wp), P(b), PR(y), P(part), M, K, N)
+        if isinstance(x, Pairs):
+            # the input was written in the pair format by the producing unit's BatchNorm-apply pass: the DMA-fed 256-wide kernel
+            wmax = _planes_amax(wp, W)
+            _track_output(y)
+            nv.call("btvae_linear_relu_stats_fwd_pairs", PR(x.data), x.data.stride(0), P(x.sc), P(_weight_image_pq(W, wmax)), P(wmax), P(b),
+                    PR(y), y.stride(0), P(part), M, K, N)
+        else:
+            _operand_maxima(_amax(x), _planes_amax(wp, W), (id(u.lin.weight), "fwd"))
+            _track_output(y)
+            _pitches(n=y)
+            _bf16(a=x, out=y)
+            nv.call("btvae_linear_relu_stats_fwd_pw", PR(x), x.stride(0), P(W), P(wp), P(b), PR(y), P(part), M, K, N)
         mean, invstd = torch.empty(N, device=dev), torch.empty(N, device=dev)
         track = u.bn.track_running_stats and u.bn.running_mean is not None
         mom = u.bn.momentum if u.bn.momentum is not None else 0.1
@@ -645,6 +666,19 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         if normed:
             return Normed(y, mean, invstd, u.bn.weight, u.bn.bias, out_pr)
         out = _rows_on_lines(M, N, dev)
+        if out_pairs and keep is None and _train_pairs_ok(M, N) and not _is16(y):
+            osc = torch.empty((M + 127) // 128, (N + 127) // 128, device=dev)
+            r, r_ld, r_sc = None, 0, None
+            if u.residual:
+                r, r_ld, r_sc = (x.data, x.data.stride(0), x.sc) if isinstance(x, Pairs) else (x, x.stride(0), None)
+            nv.call("btvae_bn_apply_fwd_pairs", PR(y), y.stride(0), P(mean), P(invstd), P(u.bn.weight), P(u.bn.bias), PR(r), r_ld, P(r_sc),
+                    PR(out), out.stride(0), P(osc), M, N)
+            res = Pairs(out, osc)
+            if saved is not None:
+                res._btvae_src = saved[-1]
+            return res
+        if isinstance(x, Pairs) and u.residual:
+            x = x.float()                             # the streaming pass adds an fp32 matrix
         res_in = _like_rows(x, y) if u.residual else None
         _track_output(out)
         _pitches(n=y, same_n=(res_in, out))
@@ -655,6 +689,8 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
             out._btvae_src = saved[-1]            # lets the Linear that reads `out` find this unit's record in the backward
     elif u.bn is None and train:
         # unit built without BatchNorm: y = relu(x W^T + b) is what the backward needs; dropout / residual on top
+        if isinstance(x, Pairs):
+            raise RuntimeError("a unit without BatchNorm reads an fp32 matrix (the caller promised BatchNorm readers)")
         y = _rows_on_lines(M, N, dev)
         _operand_maxima(_amax(x), _planes_amax(wp, W), (id(u.lin.weight), "fwd"))
         _track_output(y)
@@ -759,6 +795,10 @@ def net_forward(plan: NetPlan, x: torch.Tensor, train: bool, tape: Optional[NetT
         # eval mode: the result may stay in the pair format when everything that reads it is a hidden unit (a residual one
         # adds it in that format)
         pairs_ok = not train and (i + 1 < nt or all(len(units) > 1 for units in plan.heads.values()))
+        if train:
+            # train mode: a materialised result may be in the pair format when every reader is the Linear of a BatchNorm unit
+            readers = [plan.trunk[i + 1]] if i + 1 < nt else [units[0] for units in plan.heads.values() if len(units) > 1]
+            pairs_ok = (i + 1 < nt or all(len(units) > 1 for units in plan.heads.values())) and all(r.bn is not None and r.act for r in readers)
         h = unit_forward(u, h, train, tape.trunk if tape is not None else None, keep_normed=train and normed_ok, planes=planes, out_pairs=pairs_ok)
     out, sqs = {}, {}
     for name, units in plan.heads.items():
@@ -796,6 +836,13 @@ def _wgrad(lin: torch.nn.Linear, dy: torch.Tensor, x: torch.Tensor, x_scale, x_s
     M, N = dy.shape
     K = x.shape[1]
     ws = WS.get("wgrad", WGRAD_WS_FLOATS, dy.device)
+    if isinstance(x, Pairs):                          # the input was kept in the pair format: its pieces as they are
+        if x_scale is not None:
+            raise RuntimeError("a pair-format input is never a folded BatchNorm output")
+        _operand_maxima(_amax(dy), None, (id(lin.weight), "wgrad"), b_pairs=True)
+        _pitches(n=dy)
+        nv.call("btvae_linear_wgrad_pairs", PR(dy), PR(x.data), x.data.stride(0), P(x.sc), P(_grad_view(lin.weight)), P(ws), ws.numel(), M, N, K, int(accumulate))
+        return
     _operand_maxima(_amax(dy), _amax(x), (id(lin.weight), "wgrad"))
     _pitches(n=dy)
     _bf16(a=dy, b=x)
@@ -929,7 +976,7 @@ def _unit_backward(u: Unit, sv: Saved, g: torch.Tensor, add_to: Optional[torch.T
         r = add_to
     if _fusable(sv.x_products):
         return _dgrad_with_producer_backward(sv.x_products, dpre, u.lin.weight, r, accumulate, sv.w_planes)
-    dx = _rows_like(sv.x_in)                  # a hidden activation's gradient has its pitch; the network input's is dense
+    dx = _rows_like(sv.x_in.data if isinstance(sv.x_in, Pairs) else sv.x_in)     # a hidden activation's gradient has its pitch; the network input's is dense
     r = _like_rows(r, dx)
     src = sv.x_src
     if src is not None:

@@ -190,7 +190,17 @@ int btvae_weight_image_bf16_multi(const float* const* W, const int* N, const int
  * the unit's input, in the pair format and of the output's width, is added to the result): x_sc NULL = X is fp32 (Wsplit = the weight's fp16 planes or NULL, operand maxima through
  * btvae_gemm_operand_maxima), else X is in the pair format with block scales x_sc and Wsplit = the weight's stage
  * images made with the maximum *wmax; out_sc NULL = Out is fp32, else Out is written in the pair format (ldo % 16 == 0)
- * and out_sc receives its block scales.  Pitches count floats in both formats. */
+ * and out_sc receives its block scales.  Pitches count floats in both formats.
+ * Training-side forms (two-piece mode): btvae_linear_relu_stats_fwd_pairs = btvae_linear_relu_stats_fwd_pw on a pair-format X
+ * (Y fp32 with pitch ldy, the same statistics partials); btvae_linear_wgrad_pairs = btvae_linear_wgrad on a pair-format X (the
+ * maximum of dY through btvae_gemm_operand_maxima(slot, NULL)); btvae_bn_apply_fwd_pairs = btvae_bn_apply_fwd without dropout
+ * writing Out in the pair format, its add-in R fp32 (r_sc NULL) or in the pair format. */
+int btvae_linear_relu_stats_fwd_pairs(const void* Xp, int ldx, const float* x_sc, const void* Wimage, const float* wmax, const float* b,
+                                      float* Y, int ldy, float* stat_partials, int M, int K, int N, void* stream);
+int btvae_linear_wgrad_pairs(const float* dY, const void* Xp, int ldx, const float* x_sc, float* dW, float* ws, long long ws_floats,
+                             int M, int N, int K, int accumulate, void* stream);
+int btvae_bn_apply_fwd_pairs(const float* Y, int ldy, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             const void* R, int ldr, const float* r_sc, void* Out, int ldo, float* out_sc, int M, int N, void* stream);
 int btvae_pairs_encode(const float* X, int ldx, void* P, int ldp, float* sc, int M, int N, void* stream);
 int btvae_pairs_decode(const void* P, int ldp, const float* sc, float* X, int ldx, int M, int N, void* stream);
 long long btvae_weight_image_pq_bytes(int R, int C, int transpose);

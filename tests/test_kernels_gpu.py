@@ -1302,3 +1302,101 @@ def test_pair_format_eval_chain(dev, M, K0, H):
                 assert float((got - blk).abs().max()) <= 2.0 ** -22 * float(blk.abs().max()) + 1e-30, (bi, bj)
     finally:
         nv.set_gemm_precision("fp32")
+
+
+@pytest.mark.parametrize("M,H", [(300, 200), (520, 72), (16500, 1000)])
+def test_pair_format_training_side(dev, M, H):
+    """The train-mode entry points on pair-format activations: the BatchNorm-apply pass that writes one (no add-in, an fp32
+    add-in, a pair-format add-in), the Linear+ReLU+statistics product that reads one, the weight gradient that reads one.
+    Each against fp64 on the values the pair-format operand holds (its decode).  Tolerances: a pair-format output 2^-22 of its
+    block's maximum (2^-20 with an add-in: the scale comes from a bound on the sum); the products as their fp32-operand
+    forms."""
+    nv.set_gemm_precision("fp32_split2")
+    try:
+        L = nv.lib()
+        g = torch.Generator().manual_seed(7 * M + H)
+        ld = (H + 31) // 32 * 32
+        nb = ((M + 127) // 128, (H + 127) // 128)
+
+        def padded(t):
+            buf = torch.zeros(M, ld, device=dev)
+            buf[:, :H] = t.to(dev)
+            return buf
+
+        def pair_buffer():
+            return torch.full((M, ld), float("nan"), device=dev), torch.full(nb, float("nan"), device=dev)
+
+        def decode(buf, sc):
+            out = torch.empty(M, ld, device=dev)
+            nv.call("btvae_pairs_decode", P(buf), ld, P(sc), P(out), ld, M, ld)
+            return out
+
+        def slot(t):
+            s = torch.zeros(2, device=dev)
+            nv.call("btvae_absmax", P(t), t.numel(), P(s))
+            return s
+
+        # BatchNorm-apply writing pairs
+        Y = padded(torch.relu(torch.randn(M, H, generator=g)) * torch.logspace(-1, 1, H))
+        mean, invstd = (0.3 * torch.randn(H, generator=g)).to(dev), (0.5 + torch.rand(H, generator=g)).to(dev)
+        gamma, beta = (0.5 + torch.rand(H, generator=g)).to(dev), (0.2 * torch.randn(H, generator=g)).to(dev)
+        sc64 = (invstd * gamma).double()
+        ref0 = (Y[:, :H].double() - mean.double()) * sc64 + beta.double()
+        o0, s0 = pair_buffer()
+        nv.call("btvae_bn_apply_fwd_pairs", P(Y), ld, P(mean), P(invstd), P(gamma), P(beta), None, 0, None, P(o0), ld, P(s0), M, H)
+        d0 = decode(o0, s0)
+        assert torch.equal(d0[:, H:], torch.zeros_like(d0[:, H:])), "pad columns of a pair-format row"
+        close(d0[:, :H], ref0, 4e-7, 2.0 ** -22 * float(ref0.abs().max()), "bn apply -> pairs")
+        R = padded(torch.randn(M, H, generator=g))
+        o1, s1 = pair_buffer()
+        nv.call("btvae_bn_apply_fwd_pairs", P(Y), ld, P(mean), P(invstd), P(gamma), P(beta), P(R), ld, None, P(o1), ld, P(s1), M, H)
+        d1 = decode(o1, s1)
+        ref1 = ref0 + R[:, :H].double()
+        close(d1[:, :H], ref1, 4e-7, 2.0 ** -20 * float(ref1.abs().max()), "bn apply + fp32 add-in -> pairs")
+        o2, s2 = pair_buffer()
+        nv.call("btvae_bn_apply_fwd_pairs", P(Y), ld, P(mean), P(invstd), P(gamma), P(beta), P(o0), ld, P(s0), P(o2), ld, P(s2), M, H)
+        d2 = decode(o2, s2)
+        ref2 = ref0 + d0[:, :H].double()
+        assert torch.equal(d2[:, H:], torch.zeros_like(d2[:, H:]))
+        close(d2[:, :H], ref2, 4e-7, 2.0 ** -20 * float(ref2.abs().max()), "bn apply + pair-format add-in -> pairs")
+        # the pass without BatchNorm vectors is a plain conversion (+ add-in)
+        o3, s3 = pair_buffer()
+        nv.call("btvae_bn_apply_fwd_pairs", P(Y), ld, None, None, None, None, None, 0, None, P(o3), ld, P(s3), M, H)
+        close(decode(o3, s3)[:, :H], Y[:, :H], 0.0, 2.0 ** -22 * float(Y.abs().max()), "conversion")
+
+        # Linear + ReLU + statistics on the pair-format matrix o1
+        xv = d1[:, :H].double().cpu()
+        N = H
+        W = (torch.randn(N, H, generator=g) / math.sqrt(H)).to(dev)
+        b = (0.3 * torch.randn(N, generator=g)).to(dev)
+        wmax = slot(W)
+        img = torch.empty(L.btvae_weight_image_pq_bytes(N, H, 0), dtype=torch.uint8, device=dev)
+        nv.call("btvae_weight_image_pq", P(W), H, N, H, 0, P(img), P(wmax))
+        tiles = (M + 127) // 128
+        Yo = torch.full((M, ld), float("nan"), device=dev)
+        part = torch.empty(tiles, 2, N, device=dev)
+        nv.call("btvae_linear_relu_stats_fwd_pairs", P(o1), ld, P(s1), P(img), P(wmax), P(b), P(Yo), ld, P(part), M, H, N)
+        yref = torch.relu(xv @ W.cpu().double().t() + b.cpu().double())
+        close(Yo[:, :N], yref, 2e-6, 2e-6 * math.sqrt(H) * float(xv.abs().max()), "pairs -> relu(linear)")
+        mu, isd = torch.empty(N, device=dev), torch.empty(N, device=dev)
+        nv.call("btvae_bn_stats_finalize", P(part), tiles, M, N, P(mu), P(isd), None, None, 0.1, 1e-5)
+        yr = Yo[:, :N].cpu().double()
+        close(mu, yr.mean(0), 1e-5, 1e-6 * float(yr.abs().max()), "mean")
+        close(isd, 1 / torch.sqrt(yr.var(0, unbiased=False) + 1e-5), 2e-5, 0, "invstd")
+
+        # weight gradient with the pair-format matrix as the B operand
+        Nw = 72 if H != 72 else 200
+        ldn = (Nw + 31) // 32 * 32
+        dY = torch.zeros(M, ldn, device=dev)
+        dY[:, :Nw] = (torch.randn(M, Nw, generator=g) * torch.logspace(-2, 0, Nw)).to(dev)
+        dmax = slot(dY)
+        dW = torch.full((Nw, H), float("nan"), device=dev)
+        ws = torch.empty(8 * 1024 * 1024, device=dev)
+        for acc in (0, 1):
+            L.btvae_gemm_operand_maxima(P(dmax), None)
+            L.btvae_next_row_pitches(ldn, 0)
+            nv.call("btvae_linear_wgrad_pairs", P(dY), P(o1), ld, P(s1), P(dW), P(ws), ws.numel(), M, Nw, H, acc)
+        wref = 2.0 * (dY[:, :Nw].cpu().double().t() @ xv)
+        close(dW, wref, 2e-6, 4e-6 * math.sqrt(M) * float(dY.abs().max()) * float(xv.abs().max()) / 4.0, "wgrad on pairs")
+    finally:
+        nv.set_gemm_precision("fp32")

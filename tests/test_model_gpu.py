@@ -774,25 +774,42 @@ def _full_size_oracle():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("precision", ["fp32_split2", "fp32_split", "fp32"])
+@pytest.mark.parametrize("precision", ["fp32_split2", "fp32_split2_pairs", "fp32_split", "fp32"])
 def test_config0_full_size_step_vs_oracle(dev, precision):
     """The benchmark's own configuration -- config0 model, B=4096, S=16 (65,536 decoder rows), H=1000 -- for one train
     step in the three fp32-accurate GEMM modes against the fp64 oracle on the same seeded weights, data and noise: ELBO /
     RLL / KL at 1e-4, the pre-clip gradient norm, every gradient tensor, and the BatchNorm running statistics the
     forward leaves (statistics over 65,536 rows, the fused BatchNorm-backward epilogues and the split-reduction
-    weight gradients at M=65,536 all sit on this path)."""
+    weight gradients at M=65,536 all sit on this path).  ``fp32_split2_pairs``: the two-piece mode with the materialised
+    hidden activations of the BatchNorm units kept in the pair format (``engine.TRAIN_PAIRS``), held to the same bounds."""
     from behavio_temporal_vae_amd.vae_models import CVAE
+    from behavio_temporal_vae_amd import engine as E, _native as nv
     o = _full_size_oracle()
     torch.manual_seed(2112)
     m = CVAE(input_dim=48, conditioner=Cdim(4), **o["cfg"])
     m.load_state_dict(o["sd0"])
     m = m.to(dev).train()
+    pairs = precision.endswith("_pairs")
+    precision = precision.replace("_pairs", "")
     m.set_gemm_precision(precision)
+    calls, call0, flag0 = {}, nv.call, E.TRAIN_PAIRS
+
+    def counting(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return call0(name, *a)
     try:
+        E.TRAIN_PAIRS, nv.call = pairs, counting
         fw = m._run_forward(o["x"].to(dev), o["c"].to(dev), 16, eps=o["eps"].to(dev), tape=True)
         out = m._loss_and_backward(fw, o["x"].to(dev), 1.0).tolist()
     finally:
+        E.TRAIN_PAIRS, nv.call = flag0, call0
         m.set_gemm_precision("fp32_split2")
+    if pairs:
+        # the decoder's trunk (65,536 rows): three residual units read and write pair-format matrices
+        assert calls.get("btvae_bn_apply_fwd_pairs", 0) >= 3 and calls.get("btvae_linear_relu_stats_fwd_pairs", 0) >= 3 \
+            and calls.get("btvae_linear_wgrad_pairs", 0) >= 3, calls
+    else:
+        assert "btvae_bn_apply_fwd_pairs" not in calls
     for v, k in zip(out, ("loss", "elbo", "rll", "kl")):
         assert abs(v - o["terms"][k]) <= 1e-4 * abs(o["terms"][k]), (precision, k, v, o["terms"][k])
     gn = float(m._grad_arena.double().pow(2).sum().sqrt())

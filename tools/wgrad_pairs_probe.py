@@ -1,13 +1,11 @@
 #!/usr/bin/env python3
 """Weight gradient dW = dY^T X with X stored in the pair format (csrc/pairs.h) against the shipped two-piece product on an
-fp32 X: agreement, error against fp64, time.  Needs the experiments build:
+fp32 X: agreement, error against fp64, time.
 
-    make -C behavio_temporal_vae_amd/csrc experiments
-    BTVAE_HIP_LIB=$PWD/tools/libbtvae_exp.so python tools/wgrad_pairs_probe.py [M=65536] [N=K=1000] [reps=20]"""
+    python tools/wgrad_pairs_probe.py [M=65536] [N=K=1000] [reps=20]"""
 import os
 import sys
 import time
-from ctypes import c_int, c_void_p
 
 import torch
 
@@ -33,7 +31,6 @@ def main():
     nv.ensure_device(dev)
     nv.set_gemm_precision("fp32_split2")
     L = nv.lib()
-    L.btvae_next_wgrad_pairs.argtypes, L.btvae_next_wgrad_pairs.restype = [c_void_p], c_int
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     N = K = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
@@ -59,8 +56,7 @@ def main():
     def pairs():
         L.btvae_gemm_operand_maxima(P(ymax), None)
         L.btvae_next_row_pitches(ld, 0)
-        L.btvae_next_wgrad_pairs(P(xs))
-        nv.call("btvae_linear_wgrad", P(dY), P(Xp), ld, P(dW1), P(ws), ws.numel(), M, N, K, 0)
+        nv.call("btvae_linear_wgrad_pairs", P(dY), P(Xp), ld, P(xs), P(dW1), P(ws), ws.numel(), M, N, K, 0)
 
     shipped()
     pairs()
