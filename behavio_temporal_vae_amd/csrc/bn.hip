@@ -593,6 +593,8 @@ BTVAE_API int btvae_bn_apply_fwd(const float* Y, const float* mean, const float*
 BTVAE_API int btvae_bn_apply_fwd_pairs(const float* Y, int ldy, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                        const void* R, int ldr, const float* r_sc, void* Out, int ldo, float* out_sc, int M, int N,
                                        void* stream) {
+    // pitches are arguments here and the block scales stand in for a tensor maximum: pending requests of either kind end with this call
+    (void)take_row_pitches(); (void)take_output_maximum(); (void)take_bf16_mask();
     BTVAE_REQUIRE(Y && Out && out_sc && M > 0 && N > 0, "bn_apply_fwd_pairs: null pointer or empty");
     BTVAE_REQUIRE(mean ? (invstd && gamma && beta) : (!invstd && !gamma && !beta), "bn_apply_fwd_pairs: pass all four BatchNorm vectors or none");
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
