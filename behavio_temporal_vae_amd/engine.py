@@ -326,6 +326,15 @@ class _Guard:
             s = self.ids[key] = len(self.ids) % nv.lib().btvae_guard_sites()     # beyond the table sites share entries
         return s
 
+    def tripped(self, key, a: torch.Tensor, b: torch.Tensor) -> bool:
+        """Is the range flag of ``key``'s site up?  ``strict``: after testing the operands with maxima ``a`` / ``b`` now."""
+        s = self.site(key)
+        f = self.flags()
+        if self.strict and not f[2 * s] and not torch.cuda.is_current_stream_capturing():
+            nv.call("btvae_guard_check", P(a), P(b), s)
+            torch.cuda.current_stream().synchronize()
+        return bool(f[2 * s])
+
     def tripped_sites(self) -> int:
         return int((self.flags()[0::2] != 0).sum())
 
@@ -554,6 +563,9 @@ class Pairs:
         return out[:, :N]
 
 
+_PAIR_CHAIN = {"refused": False}       # this pass over a network: the range guard has refused to start a pair-format chain
+
+
 def _eval_pairs_ok(M: int, N: int) -> bool:
     """May an eval-mode unit with ``M`` rows of width ``N`` hand its output on in the pair format?  Two-piece mode, enough
     rows, rows on a pitch that is a multiple of 16 floats, 16-byte column groups."""
@@ -718,6 +730,15 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
             nv.call("btvae_bn_fold_eval", P(u.bn.weight), P(u.bn.bias), P(u.bn.running_mean), P(u.bn.running_var), float(u.bn.eps), P(scale), P(shift), N)
         pairs_in = isinstance(x, Pairs)
         out_pairs = out_pairs and (pairs_in or not u.residual) and _eval_pairs_ok(M, N)      # a residual unit adds a pair-format input only
+        if out_pairs and not pairs_in and GUARD.enabled and (
+                _PAIR_CHAIN["refused"] or GUARD.tripped((id(u.lin.weight), "fwd"), _amax(x), _planes_amax(wp, W))):
+            # The chain would start here, and this product's range flag is up: its input has rows or columns far below the
+            # tensor's maximum.  What such an input does to a hidden activation (one row 2^20 above its neighbours in a block)
+            # a block scale cannot hold either, and a pair-format operand has no three-piece form: for the rest of this pass
+            # over the network the activations stay fp32, where every product has its own guard.
+            out_pairs = False
+            _PAIR_CHAIN["refused"] = True
+            GUARD.fallbacks += 1
         if pairs_in or out_pairs:
             if u.residual and not pairs_in:
                 raise RuntimeError("a residual unit in the pair-format chain needs its input in that format")
@@ -786,6 +807,7 @@ def net_forward(plan: NetPlan, x: torch.Tensor, train: bool, tape: Optional[NetT
     h = x
     nt = len(plan.trunk)
     MAX_SLOTS.fresh()
+    _PAIR_CHAIN["refused"] = False
     planes = _plan_planes(plan, tape is not None)
     for i, u in enumerate(plan.trunk):
         if i + 1 < nt:

@@ -612,3 +612,65 @@ def test_eval_chain_in_pair_format_equals_fp32_chain(dev):
     assert (N * 20, 200) in seen, seen              # the decoder's trunk handed pair-format activations on
     assert torch.allclose(ra, rb, rtol=1e-6, atol=1e-5 * float(ra.abs().max()))
     assert torch.allclose(a, b, rtol=1e-6, atol=1e-5 * float(a.abs().max()))
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_eval_pair_chain_stays_fp32_behind_a_flagged_input(dev, strict):
+    """A pair-format activation has one scale per 128 x 128 block and no three-piece form.  A decoder input with one row 2^24
+    times the others (here: one profile's conditions) gives hidden activations with such a row, next to which the other rows of
+    its block would keep nothing of their values.  The chain starts only while the range flag of its first product is down: with the test made
+    before every product (strict) no pair-format activation is ever written and the scores of the other profiles meet the
+    fp32-instruction chain at 1e-4; without waiting, the first call raises the flag and the next one stays fp32."""
+    from behavio_temporal_vae_amd import engine as E, testing_lib
+    from behavio_temporal_vae_amd.vae_models import CVAE
+    cfg = {"latent_dim": 24, "distribution_dict": {
+        "posterior": {"dist_type": "normal", "sigma_lim": 0.05, "mu_upper_lim": 5.0, "mu_lower_lim": -5.0, "num_neurons": 200,
+                      "num_hidden_layers": 2, "dropout": False, "batch_normalization": True},
+        "likelihood": {"dist_type": "dict-gauss", "vocab_size": 100, "sigma_lim": 1e-6, "marginal_std_lim": 0.05, "mu_lower_lim": -3,
+                       "num_neurons": 200, "num_hidden_layers": 3, "dropout": False, "batch_normalization": True}}}
+
+    class C4:
+        cond_dim = 4
+    torch.manual_seed(5)
+    m = CVAE(input_dim=24, conditioner=C4(), **cfg).to(dev).eval()
+    assert m.gemm_precision == "fp32_split2"
+    N, K = 300, 40
+    gen = torch.Generator().manual_seed(16)
+    x, c = torch.randn(N, 24, generator=gen).to(dev), torch.randn(N, 4, generator=gen).to(dev)
+    c[7] *= 2.0 ** 24
+    eps = torch.randn(K, N, 24, generator=gen).to(dev)
+    others = torch.ones(N, dtype=torch.bool, device=dev)
+    others[7] = False
+    keep_rows, was = E.EVAL_PAIRS_MIN_ROWS, E.GUARD.strict
+    seen = []
+    orig = E.Pairs.__init__
+
+    def spy(self, data, sc):
+        seen.append(tuple(data.shape))
+        orig(self, data, sc)
+    try:
+        m.set_gemm_precision("fp32")
+        ref, rref, _ = testing_lib.iw_loglikelihood_device(m, x, c, K, mc_sample_batch_size=20, eps=eps, return_rlls=True)
+        m.set_gemm_precision("fp32_split2")
+        E.GUARD.reset()
+        E.GUARD.strict = strict
+        E.EVAL_PAIRS_MIN_ROWS = 0
+        E.Pairs.__init__ = spy
+        got, rgot, _ = testing_lib.iw_loglikelihood_device(m, x, c, K, mc_sample_batch_size=20, eps=eps, return_rlls=True)
+        torch.cuda.synchronize()
+        assert E.GUARD.tripped_sites() > 0
+        if not strict:
+            assert seen, "the first chunks ran before the host saw a flag"
+            del seen[:]
+            got, rgot, _ = testing_lib.iw_loglikelihood_device(m, x, c, K, mc_sample_batch_size=20, eps=eps, return_rlls=True)
+        assert not seen, seen                        # no pair-format activation behind the flagged product
+        assert E.GUARD.fallbacks > 0
+        E.GUARD.check()
+    finally:
+        E.EVAL_PAIRS_MIN_ROWS, E.GUARD.strict = keep_rows, was
+        E.Pairs.__init__ = orig
+        E.GUARD.reset()
+        m.set_gemm_precision("fp32_split2")
+    assert torch.allclose(rgot[:, others], rref[:, others], rtol=1e-4, atol=1e-4 * float(rref[:, others].abs().max())), \
+        float((rgot[:, others] - rref[:, others]).abs().max())
+    assert torch.allclose(got[others], ref[others], rtol=1e-4, atol=1e-4 * float(ref[others].abs().max()))
