@@ -250,11 +250,13 @@ def prof_filter(kinds=None, min_flops: float = 0.0):
     lib().btvae_prof_filter(mask, float(min_flops))
 
 
-def prof_dominant(kind: str):
+def prof_dominant(kind: str, operands: str = "any"):
     """(ms summed, flops of one launch, launches) of the launches of ``kind`` with the largest FLOP count;
-    call after a device sync and before ``prof_collect``."""
+    call after a device sync and before ``prof_collect``.  ``operands``: "any", or only the launches on "plain" (fp32 / bf16)
+    operands, or only those with an operand in the "pairs" format (one shape can run on two kernels)."""
     ms, fl, cnt = c_double(), c_double(), c_longlong()
-    rc = lib().btvae_prof_dominant(PROF_KINDS.index(kind), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt))
+    sel = ("any", "plain", "pairs").index(operands)
+    rc = lib().btvae_prof_dominant(PROF_KINDS.index(kind) + 256 * sel, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt))
     if rc != 0:
         raise RuntimeError(last_error())
     return ms.value, fl.value, cnt.value

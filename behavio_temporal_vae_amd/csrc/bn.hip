@@ -221,16 +221,18 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_pairs_kernel(const float* __
     for (int j = 0; j < 16; ++j) {
         const int r = r0 + 8 * j;
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (RF == 2)                                  // lane pairs read 16 bytes each (columns past N inside the pitch hold zeros)
+            q = btvae_pairs::pq_load4_paired(reinterpret_cast<const unsigned short*>(R) + (size_t)min(r, M - 1) * (2 * ldr), c, rinv, tid & 1,
+                                             r < M && (c & ~7) < N);
         if (r < M && ok) {
             const nat_f4 y = *reinterpret_cast<const nat_f4*>(Y + (size_t)r * ldy + c);
             v[j] = make_float4(y.x * sc[0] + sh[0], y.y * sc[1] + sh[1], y.z * sc[2] + sh[2], y.w * sc[3] + sh[3]);
             if (RF == 1) {
-                const nat_f4 q = *reinterpret_cast<const nat_f4*>(R + (size_t)r * ldr + c);
-                v[j].x += q.x; v[j].y += q.y; v[j].z += q.z; v[j].w += q.w;
-            } else if (RF == 2) {
-                const float4 q = btvae_pairs::pq_load4(reinterpret_cast<const unsigned short*>(R) + (size_t)r * (2 * ldr), c, rinv);
-                v[j].x += q.x; v[j].y += q.y; v[j].z += q.z; v[j].w += q.w;
+                const nat_f4 f = *reinterpret_cast<const nat_f4*>(R + (size_t)r * ldr + c);
+                q = make_float4(f.x, f.y, f.z, f.w);
             }
+            if (RF != 0) { v[j].x += q.x; v[j].y += q.y; v[j].z += q.z; v[j].w += q.w; }
         }
         m = amax4(m, v[j]);
     }
@@ -239,12 +241,11 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_pairs_kernel(const float* __
     __syncthreads();
     const float s = btvae_pairs::pq_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
     if (tid == 0) out_sc[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
-    if (c < ldo) {                                    // columns between N and the pitch: zeros (v is zero there)
+    // columns between N and the pitch: zeros (v is zero there).  Lane pairs write 16 bytes each: whole 64-byte groups per wave store.
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int r = r0 + 8 * j;
-            if (r < M) btvae_pairs::pq_store4(Out + (size_t)r * (2 * ldo), c, v[j], s);
-        }
+    for (int j = 0; j < 16; ++j) {
+        const int r = r0 + 8 * j;
+        btvae_pairs::pq_store4_paired(Out + (size_t)min(r, M - 1) * (2 * ldo), c, v[j], s, tid & 1, r < M && c < ldo);
     }
 }
 

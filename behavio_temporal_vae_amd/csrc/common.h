@@ -24,12 +24,12 @@ enum ProfKind : int {
     PK_OPTIM = 7,        // gradient norm + Adam
     PK_COUNT = 8
 };
-void prof_begin(int kind, hipStream_t s, double flops, double bytes);
+void prof_begin(int kind, hipStream_t s, double flops, double bytes, int tag = 0);   // tag 1: a launch with a pair-format operand
 void prof_end(int kind, hipStream_t s);
 
 struct ProfScope {
     int kind; hipStream_t s;
-    ProfScope(int k, hipStream_t st, double flops, double bytes) : kind(k), s(st) { prof_begin(k, st, flops, bytes); }
+    ProfScope(int k, hipStream_t st, double flops, double bytes, int tag = 0) : kind(k), s(st) { prof_begin(k, st, flops, bytes, tag); }
     ~ProfScope() { prof_end(kind, s); }
 };
 

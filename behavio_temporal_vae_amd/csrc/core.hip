@@ -19,7 +19,7 @@ int set_error(const char* fmt, ...) {
     return 1;
 }
 
-struct ProfRec { int kind; hipEvent_t e0, e1; double flops, bytes; };
+struct ProfRec { int kind; hipEvent_t e0, e1; double flops, bytes; int tag; };
 static bool g_prof_on = false;
 static unsigned g_kind_mask = ~0u;     // families that are timed while g_prof_on
 static double g_min_flops = 0.0;       // ... and only launches at or above this FLOP count
@@ -35,11 +35,11 @@ static hipEvent_t get_event() {
     return e;
 }
 
-void prof_begin(int kind, hipStream_t s, double flops, double bytes) {
+void prof_begin(int kind, hipStream_t s, double flops, double bytes, int tag) {
     if (!g_prof_on) return;
     if (!((g_kind_mask >> kind) & 1u) || flops < g_min_flops) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    ProfRec r{kind, get_event(), get_event(), flops, bytes};
+    ProfRec r{kind, get_event(), get_event(), flops, bytes, tag};
     if (!r.e0 || !r.e1 || hipEventRecord(r.e0, s) != hipSuccess) {      // timing is best effort: leave this launch untimed
         (void)hipGetLastError();
         if (r.e0) g_free.push_back(r.e0);
@@ -205,15 +205,21 @@ BTVAE_API int btvae_prof_filter(unsigned kind_mask, double min_flops) {
 
 // After a device synchronisation and before btvae_prof_collect: within one family, the launches that carry the
 // largest FLOP count (the family's dominant shape) -- summed milliseconds, FLOPs of one such launch, launches.
+// kind = family + 256 * selection: selection 0 all of those launches, 1 only the ones on fp32 / bf16 operands, 2 only the
+// ones with an operand in the pair format (one shape can run on two kernels).
 BTVAE_API int btvae_prof_dominant(int kind, double* ms, double* flops_per_launch, long long* count) {
-    BTVAE_REQUIRE(kind >= 0 && kind < PK_COUNT && ms && flops_per_launch && count, "prof_dominant: bad argument");
+    const int sel = kind >> 8;
+    kind &= 255;
+    BTVAE_REQUIRE(kind >= 0 && kind < PK_COUNT && sel >= 0 && sel <= 2 && ms && flops_per_launch && count, "prof_dominant: bad argument");
     std::lock_guard<std::mutex> lk(g_mu);
     double top = 0.0;
     for (auto& r : g_recs) if (r.kind == kind && r.flops > top) top = r.flops;
     *ms = 0.0; *flops_per_launch = top; *count = 0;
     for (auto& r : g_recs) {
         float t = 0.f;
-        if (r.kind == kind && r.flops >= 0.999 * top && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { *ms += t; *count += 1; }
+        if (r.kind == kind && (sel == 0 || r.tag == sel - 1) && r.flops >= 0.999 * top && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
+            *ms += t; *count += 1;
+        }
     }
     return 0;
 }

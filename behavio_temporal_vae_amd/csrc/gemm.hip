@@ -1111,7 +1111,7 @@ BTVAE_API int btvae_linear_relu_stats_fwd_pq256(const void* Xp, int ldx, const f
     BTVAE_REQUIRE(b && stat_partials, "linear_relu_stats_fwd_pq256: null bias/stats");
     GemmArgs a{}; a.A = (const float*)Xp; a.lda = ldx; a.a_sc = xsc; a.C = Y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
     a.bias = b; a.stats = stat_partials; a.Bp = (const unsigned short*)Wimage; a.amax_b = wmax;
-    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), 1);
     return launch_pq256<EPI_RELU_STATS>(a, groups, (hipStream_t)stream, "linear_relu_stats_fwd_pq256");
 }
 
@@ -1160,7 +1160,7 @@ BTVAE_API int btvae_linear_relu_affine_fwd_pairs(const void* X, int ldx, const f
                   "linear_relu_affine_fwd_pairs: pair-format output needs N %% 4 == 0, a 16-byte aligned base and a pitch that is a multiple of 16 (N %d, pitch %d)", N, ldo);
     GemmArgs a{}; a.C = (float*)Out; a.ldc = ldo; a.M = M; a.N = N; a.K = K;
     a.bias = b; a.scale = scale; a.shift = shift; a.c_sc = out_sc; a.c_scn = (N + 127) / 128;
-    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), x_sc ? 1 : 0);
     if (x_sc) {
         BTVAE_REQUIRE(g_precision.load(std::memory_order_relaxed) == 3, "linear_relu_affine_fwd_pairs: pair-format operands belong to the two-piece mode");
         BTVAE_REQUIRE(Wsplit && wmax, "linear_relu_affine_fwd_pairs: a pair-format operand needs the weight's stage images and its maximum");
@@ -1314,7 +1314,7 @@ static int matmul_tn_impl(const float* A, int lda, const float* B, int ldb, floa
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const size_t out_elems = (size_t)M * N;
     int splits = pick_splits(tiles, K, ws ? (size_t)ws_floats : 0, out_elems);
-    ProfScope ps(prof_kind, s, 2.0 * M * N * K, 4.0 * ((double)K * M + (double)K * N + (double)M * N));
+    ProfScope ps(prof_kind, s, 2.0 * M * N * K, 4.0 * ((double)K * M + (double)K * N + (double)M * N), b_sc ? 1 : 0);
     const bool reduced_ok = prof_kind == PK_GEMM_WGRAD;
     if (splits == 1 && !accumulate && !scale) {
         a.C = C;

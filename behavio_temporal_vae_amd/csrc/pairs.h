@@ -66,4 +66,29 @@ __device__ __forceinline__ float4 pq_load4(const unsigned short* row, int c, flo
     return v;
 }
 
+// The same for two neighbouring lanes (lane and lane ^ 1: the even one at c % 8 == 0, the odd one at c + 4 of the same row),
+// 16-byte accesses: the even lane moves the eight high pieces of the pair's columns, the odd lane the eight low ones, and
+// they swap halves in registers.  Every lane of the pair must be active at the call.
+typedef unsigned pq_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned pq_swap1(unsigned x) {            // the value lane ^ 1 holds
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void pq_store4_paired(unsigned short* row, int c, const float4 v, float s, bool odd, bool on) {
+    unsigned P0, Q0, P1, Q1;
+    pq_encode2(v.x, v.y, s, P0, Q0);
+    pq_encode2(v.z, v.w, s, P1, Q1);
+    const unsigned r0 = pq_swap1(odd ? P0 : Q0), r1 = pq_swap1(odd ? P1 : Q1);
+    const pq_u4 w = odd ? pq_u4{r0, r1, Q0, Q1} : pq_u4{P0, P1, r0, r1};
+    if (on) *reinterpret_cast<pq_u4*>(row + pq_col(c & ~7) + (odd ? 16 : 0)) = w;
+}
+__device__ __forceinline__ float4 pq_load4_paired(const unsigned short* row, int c, float inv, bool odd, bool on) {
+    pq_u4 w = {0u, 0u, 0u, 0u};
+    if (on) w = *reinterpret_cast<const pq_u4*>(row + pq_col(c & ~7) + (odd ? 16 : 0));
+    const unsigned r0 = pq_swap1(odd ? w.x : w.z), r1 = pq_swap1(odd ? w.y : w.w);
+    float4 v;
+    pq_decode2(odd ? r0 : w.x, odd ? w.z : r0, inv, v.x, v.y);
+    pq_decode2(odd ? r1 : w.y, odd ? w.w : r1, inv, v.z, v.w);
+    return v;
+}
+
 }  // namespace btvae_pairs

@@ -335,6 +335,20 @@ class _Guard:
             torch.cuda.current_stream().synchronize()
         return bool(f[2 * s])
 
+    def pairs_ok(self, key, a: Optional[torch.Tensor], b: Optional[torch.Tensor], watch: bool = True) -> bool:
+        """May ``key``'s product run on a pair-format operand (which has no three-piece form)?  Not once the site's range flag
+        is up.  The kernels that read pairs test only the operands they split themselves, so the maxima given here (``a`` /
+        ``b``: those of the other operand, e.g. the weight of a forward product) are tested by a launch of their own:
+        waited for when ``strict``, else (``watch``) seen by the next pass; ``watch=False`` when the product tests them itself."""
+        if not self.enabled:
+            return True
+        if self.tripped(key, a, b):
+            self.fallbacks += 1
+            return False
+        if watch and not self.strict and (a is not None or b is not None):
+            nv.call("btvae_guard_check", P(a), P(b), self.site(key))
+        return True
+
     def tripped_sites(self) -> int:
         return int((self.flags()[0::2] != 0).sum())
 
@@ -534,7 +548,7 @@ EVAL_PAIRS_MIN_ROWS = int(os.environ.get("BTVAE_EVAL_PAIRS_MIN_ROWS", "65536"))
 # Training: the output of a BatchNorm-apply pass (a unit whose result has to exist in memory: it feeds a residual unit or is one)
 # in the pair format when every reader is a BatchNorm unit's Linear -- that Linear's forward product and its weight gradient
 # take the pieces as they are, a residual reader adds them.  From the same row count on as the eval-mode chains.
-TRAIN_PAIRS = os.environ.get("BTVAE_TRAIN_PAIRS", "0") == "1"
+TRAIN_PAIRS = os.environ.get("BTVAE_TRAIN_PAIRS", "1") == "1"
 TRAIN_PAIRS_MIN_ROWS = int(os.environ.get("BTVAE_TRAIN_PAIRS_MIN_ROWS", "65536"))
 
 
@@ -556,11 +570,18 @@ class Pairs:
         return self.data.device
 
     def float(self) -> torch.Tensor:
-        """The values as an fp32 matrix (tests, debugging)."""
+        """The values as an fp32 matrix with the same row pitch (the pad columns decode to the zeros they hold), its maximum
+        taken: what a consumer falls back to when its guard refuses the pair format; tests."""
         M, N = self.data.shape
-        out = torch.empty(M, self.data.stride(0), device=self.data.device)
-        nv.call("btvae_pairs_decode", PR(self.data), self.data.stride(0), P(self.sc), P(out), out.stride(0), M, (N + 7) // 8 * 8)
-        return out[:, :N]
+        ld = self.data.stride(0)
+        full = torch.empty(M, ld, device=self.data.device)
+        nv.call("btvae_pairs_decode", PR(self.data), ld, P(self.sc), P(full), ld, M, ld if ld % 8 == 0 else (N + 7) // 8 * 8)
+        out = full if ld == N else full[:, :N]
+        if _split_mode() == 2:
+            slot = MAX_SLOTS.take(full.device)
+            nv.call("btvae_absmax", P(full), full.numel(), P(slot))
+            out._btvae_amax = slot
+        return out
 
 
 _PAIR_CHAIN = {"refused": False}       # this pass over a network: the range guard has refused to start a pair-format chain
@@ -640,6 +661,8 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         tiles = (M + 127) // 128
         y = _rows_on_lines(M, N, dev)
         part = WS.get("bnpart", tiles * 2 * N, dev)
+        if isinstance(x, Pairs) and not GUARD.pairs_ok((id(u.lin.weight), "fwd"), None, _planes_amax(wp, W)):
+            x = x.float()                             # the weight has regions far below its maximum: the guarded fp32-operand product
         if isinstance(x, Pairs):
             # the input was written in the pair format by the producing unit's BatchNorm-apply pass: the DMA-fed 256-wide kernel
             wmax = _planes_amax(wp, W)
@@ -728,6 +751,9 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
         if u.bn is not None:
             scale, shift = torch.empty(N, device=dev), torch.empty(N, device=dev)
             nv.call("btvae_bn_fold_eval", P(u.bn.weight), P(u.bn.bias), P(u.bn.running_mean), P(u.bn.running_var), float(u.bn.eps), P(scale), P(shift), N)
+        if isinstance(x, Pairs) and not GUARD.pairs_ok((id(u.lin.weight), "fwd"), None, _planes_amax(wp, W)):
+            x = x.float()                             # as in train mode; the rest of the pass stays fp32
+            _PAIR_CHAIN["refused"] = True
         pairs_in = isinstance(x, Pairs)
         out_pairs = out_pairs and (pairs_in or not u.residual) and _eval_pairs_ok(M, N)      # a residual unit adds a pair-format input only
         if out_pairs and not pairs_in and GUARD.enabled and (
@@ -858,6 +884,8 @@ def _wgrad(lin: torch.nn.Linear, dy: torch.Tensor, x: torch.Tensor, x_scale, x_s
     M, N = dy.shape
     K = x.shape[1]
     ws = WS.get("wgrad", WGRAD_WS_FLOATS, dy.device)
+    if isinstance(x, Pairs) and not GUARD.pairs_ok((id(lin.weight), "wgrad"), _amax(dy), None, watch=False):
+        x = x.float()                                 # dY has tripped this site's range flag before: three exact pieces on fp32 operands
     if isinstance(x, Pairs):                          # the input was kept in the pair format: its pieces as they are
         if x_scale is not None:
             raise RuntimeError("a pair-format input is never a folded BatchNorm output")

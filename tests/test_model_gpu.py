@@ -774,14 +774,15 @@ def _full_size_oracle():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("precision", ["fp32_split2", "fp32_split2_pairs", "fp32_split", "fp32"])
+@pytest.mark.parametrize("precision", ["fp32_split2", "fp32_split2_fp32_activations", "fp32_split", "fp32"])
 def test_config0_full_size_step_vs_oracle(dev, precision):
     """The benchmark's own configuration -- config0 model, B=4096, S=16 (65,536 decoder rows), H=1000 -- for one train
     step in the three fp32-accurate GEMM modes against the fp64 oracle on the same seeded weights, data and noise: ELBO /
     RLL / KL at 1e-4, the pre-clip gradient norm, every gradient tensor, and the BatchNorm running statistics the
     forward leaves (statistics over 65,536 rows, the fused BatchNorm-backward epilogues and the split-reduction
-    weight gradients at M=65,536 all sit on this path).  ``fp32_split2_pairs``: the two-piece mode with the materialised
-    hidden activations of the BatchNorm units kept in the pair format (``engine.TRAIN_PAIRS``), held to the same bounds."""
+    weight gradients at M=65,536 all sit on this path).  The two-piece mode keeps the materialised hidden activations between
+    BatchNorm units in the pair format from 65,536 rows on (``engine.TRAIN_PAIRS``); ``fp32_split2_fp32_activations`` is that
+    mode without them, held to the same bounds."""
     from behavio_temporal_vae_amd.vae_models import CVAE
     from behavio_temporal_vae_amd import engine as E, _native as nv
     o = _full_size_oracle()
@@ -789,8 +790,8 @@ def test_config0_full_size_step_vs_oracle(dev, precision):
     m = CVAE(input_dim=48, conditioner=Cdim(4), **o["cfg"])
     m.load_state_dict(o["sd0"])
     m = m.to(dev).train()
-    pairs = precision.endswith("_pairs")
-    precision = precision.replace("_pairs", "")
+    pairs = precision == "fp32_split2"
+    precision = precision.replace("_fp32_activations", "")
     m.set_gemm_precision(precision)
     calls, call0, flag0 = {}, nv.call, E.TRAIN_PAIRS
 
@@ -805,9 +806,10 @@ def test_config0_full_size_step_vs_oracle(dev, precision):
         E.TRAIN_PAIRS, nv.call = flag0, call0
         m.set_gemm_precision("fp32_split2")
     if pairs:
-        # the decoder's trunk (65,536 rows): three residual units read and write pair-format matrices
-        assert calls.get("btvae_bn_apply_fwd_pairs", 0) >= 3 and calls.get("btvae_linear_relu_stats_fwd_pairs", 0) >= 3 \
-            and calls.get("btvae_linear_wgrad_pairs", 0) >= 3, calls
+        # the decoder (65,536 rows): the outputs of the trunk's first three units are written as pairs (the last one stays a
+        # folded BatchNorm in front of the heads); units two to four read them, forward and in their weight gradients
+        assert calls.get("btvae_bn_apply_fwd_pairs", 0) == 3 and calls.get("btvae_linear_relu_stats_fwd_pairs", 0) == 3 \
+            and calls.get("btvae_linear_wgrad_pairs", 0) == 3, calls
     else:
         assert "btvae_bn_apply_fwd_pairs" not in calls
     for v, k in zip(out, ("loss", "elbo", "rll", "kl")):
@@ -870,8 +872,9 @@ def test_two_piece_guard_in_a_training_step(dev, strict):
     m = m.to(dev).train()
     assert m.gemm_precision == "fp32_split2"
     E.GUARD.reset()
-    was = E.GUARD.strict
+    was, rows_was = E.GUARD.strict, E.TRAIN_PAIRS_MIN_ROWS
     E.GUARD.strict = strict
+    E.TRAIN_PAIRS_MIN_ROWS = 0                    # pair-format activations at this size too: a flagged site must leave them
     try:
         xd, cd, ed = x.to(dev), c.to(dev), eps.to(dev)
         fw = m._run_forward(xd, cd, S, eps=ed, tape=True)
@@ -887,7 +890,7 @@ def test_two_piece_guard_in_a_training_step(dev, strict):
             assert E.GUARD.fallbacks > 0
         E.GUARD.check()                                                 # nothing overflowed
     finally:
-        E.GUARD.strict = was
+        E.GUARD.strict, E.TRAIN_PAIRS_MIN_ROWS = was, rows_was
         E.GUARD.reset()
     for v, k in zip(out, ("loss", "elbo", "rll", "kl")):
         assert abs(v - terms[k]) <= 1e-4 * abs(terms[k]), (strict, k, v, terms[k])

@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 # leg key of bench.recorded_traffic -> (regex on the kernel name, workgroups of the launch, threads per workgroup)
 LEGS = {
     "training_fwd:fp32_split2:65536": (r"gemm_split_mfma<0, 0, 2, true, 2, 1, 0>", 512 * 8, 256),
+    "training_fwd_pairs:fp32_split2:65536": (r"gemm_pq256<2, 2, 0>", 256 * 4, 512),
     "training_dgrad_gstats:fp32_split2:65536": (r"gemm_split_mfma<0, 1, 7, true, 2, 1, 0>", 512 * 8, 256),
     "training_dgrad_bnbwd:fp32_split2:65536": (r"gemm_split_mfma<0, 1, 6, true, 2, 1, 0>", 512 * 8, 256),
     "scoring_fwd_pairs:fp32_split2:819200": (r"gemm_pq256<3, 2, 0>", 3200 * 4, 512),
