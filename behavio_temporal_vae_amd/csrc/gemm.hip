@@ -1140,7 +1140,7 @@ BTVAE_API int btvae_linear_relu_stats_fwd_pairs(const void* Xp, int ldx, const f
     BTVAE_REQUIRE(ldy >= N, "linear_relu_stats_fwd_pairs: row pitch %d below N = %d", ldy, N);
     GemmArgs a{}; a.A = (const float*)Xp; a.lda = ldx; a.a_sc = x_sc; a.C = Y; a.ldc = ldy; a.M = M; a.N = N; a.K = K;
     a.bias = b; a.stats = stat_partials; a.Bp = (const unsigned short*)Wimage; a.amax_b = wmax;
-    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    ProfScope ps(PK_GEMM_FWD, (hipStream_t)stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), 1);
     const int wide_tiles = ((M + 255) / 256) * ((N + QN - 1) / QN);
     return launch_pq256<EPI_RELU_STATS>(a, wide_tiles >= 256 ? 2 : 1, (hipStream_t)stream, "linear_relu_stats_fwd_pairs");
 }
