@@ -27,7 +27,8 @@ int btvae_prof_enabled(void);
 /* Time only the families in kind_mask (bit k = family k) and launches of at least min_flops; (~0u, 0) = everything. */
 int btvae_prof_filter(unsigned kind_mask, double min_flops);
 int btvae_prof_collect(double* ms, double* flops, double* bytes, long long* launches, int n);
-/* Before btvae_prof_collect: the launches of one family with the largest FLOP count (its dominant shape). */
+/* Before btvae_prof_collect: the launches of one family with the largest FLOP count (its dominant shape).  kind = family
+ * + 256 * selection: 0 all of them, 1 only those on fp32 / bf16 operands, 2 only those with an operand in the pair format. */
 int btvae_prof_dominant(int kind, double* ms, double* flops_per_launch, long long* count);
 
 /* Operand precision of the matrix products.  0 = the fp32 MFMA instruction (the mode the library starts in; the
