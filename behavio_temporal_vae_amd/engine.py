@@ -596,6 +596,8 @@ def _eval_pairs_ok(M: int, N: int) -> bool:
 
 
 def _train_pairs_ok(M: int, N: int) -> bool:
+    """May a train-mode BatchNorm unit with ``M`` rows of width ``N`` write its materialised output in the pair format?
+    The conditions of ``_eval_pairs_ok`` with the training switch and threshold."""
     pitch = -(-N // ROW_LINE_FLOATS) * ROW_LINE_FLOATS
     return (TRAIN_PAIRS and M >= TRAIN_PAIRS_MIN_ROWS and _split_mode() == 2 and PRESPLIT_WEIGHTS and N % 4 == 0
             and (PITCHED_ROWS or pitch == N))
@@ -632,7 +634,10 @@ def unit_forward(u: Unit, x, train: bool, saved: Optional[List[Saved]], keep_nor
     the result is a plain (non-residual) Linear, and a BatchNorm unit without dropout returns a ``Normed``.
     ``planes``: pre-split weights of the network made at the start of the pass (``_plan_planes``).
     Eval mode: ``x`` may be a ``Pairs``; with ``out_pairs`` the caller promises that every consumer of the result is an
-    eval-mode hidden unit, and the result is a ``Pairs`` when the unit can write one."""
+    eval-mode hidden unit, and the result is a ``Pairs`` when the unit can write one.
+    Train mode: ``x`` may be a ``Pairs`` for a BatchNorm unit; with ``out_pairs`` the caller promises that every consumer is
+    the Linear of a BatchNorm unit, and a materialised result (no ``Normed``, no dropout) is a ``Pairs`` from
+    ``TRAIN_PAIRS_MIN_ROWS`` rows on.  A consumer whose guard site is flagged decodes its input and runs the fp32-operand path."""
     M, K = x.shape
     N = u.lin.out_features
     dev = x.device
