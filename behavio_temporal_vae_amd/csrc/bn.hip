@@ -193,16 +193,18 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
 }
 
 // The same pass writing its output in the pair format (pairs.h): one workgroup per 128 x 128 block, which is what a block
-// scale spans -- thread t holds columns 4 (t & 31) .. + 3 of rows (t >> 5) + 8 j, the block's largest |value| decides the
+// scale spans -- thread t of 512 holds columns 4 (t & 31) .. + 3 of rows (t >> 5) + 16 j (eight rows: 256 threads with sixteen
+// rows each need twice the registers and run 4-6 % slower, 1024 threads no faster), the block's largest |value| decides the
 // scale before anything is written.  Y is fp32 (pitch ldy); the add-in R (the unit's input, pitch ldr) is absent (RF 0), fp32
 // (RF 1) or itself in the pair format with block scales r_sc (RF 2).  No dropout flags.
+constexpr int PAIRS_WG = 512, PAIRS_ROWS = 128 * 32 / PAIRS_WG;     // threads per 128 x 128 block, rows per thread
 template <int RF>
-__global__ __launch_bounds__(256) void bn_apply_fwd_pairs_kernel(const float* __restrict__ Y, int ldy, const float* __restrict__ mean,
+__global__ __launch_bounds__(PAIRS_WG) void bn_apply_fwd_pairs_kernel(const float* __restrict__ Y, int ldy, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, const float* __restrict__ R, int ldr,
                                                                  const float* __restrict__ r_sc, unsigned short* __restrict__ Out, int ldo,
                                                                  float* __restrict__ out_sc, int M, int N) {
-    __shared__ float red[4];
+    __shared__ float red[PAIRS_WG / 64];
     const int tid = threadIdx.x, r0 = blockIdx.y * 128 + (tid >> 5), c = blockIdx.x * 128 + ((tid & 31) << 2);
     const bool ok = c < N;                            // N % 4 == 0: a 4-column group is in or out as a whole
     float sc[4], sh[4];
@@ -215,11 +217,11 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_pairs_kernel(const float* __
     }
     float rinv = 1.f;
     if (RF == 2) rinv = btvae_pairs::pq_inv(r_sc[(size_t)blockIdx.y * gridDim.x + blockIdx.x]);
-    float4 v[16];
+    float4 v[PAIRS_ROWS];
     float m = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int r = r0 + 8 * j;
+    for (int j = 0; j < PAIRS_ROWS; ++j) {
+        const int r = r0 + (PAIRS_WG / 32) * j;
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
         if (RF == 2)                                  // lane pairs read 16 bytes each (columns past N inside the pitch hold zeros)
@@ -239,12 +241,15 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_pairs_kernel(const float* __
     m = wave_max(m);
     if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
-    const float s = btvae_pairs::pq_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    float bm = red[0];
+#pragma unroll
+    for (int w = 1; w < PAIRS_WG / 64; ++w) bm = fmaxf(bm, red[w]);
+    const float s = btvae_pairs::pq_scale_for(bm);
     if (tid == 0) out_sc[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
     // columns between N and the pitch: zeros (v is zero there).  Lane pairs write 16 bytes each: whole 64-byte groups per wave store.
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int r = r0 + 8 * j;
+    for (int j = 0; j < PAIRS_ROWS; ++j) {
+        const int r = r0 + (PAIRS_WG / 32) * j;
         btvae_pairs::pq_store4_paired(Out + (size_t)min(r, M - 1) * (2 * ldo), c, v[j], s, tid & 1, r < M && c < ldo);
     }
 }
@@ -607,9 +612,9 @@ BTVAE_API int btvae_bn_apply_fwd_pairs(const float* Y, int ldy, const float* mea
     unsigned short* out = reinterpret_cast<unsigned short*>(Out);
     const float* r = reinterpret_cast<const float*>(R);
     hipStream_t s = (hipStream_t)stream;
-    if (!R)        hipLaunchKernelGGL((bn_apply_fwd_pairs_kernel<0>), grid, dim3(256), 0, s, Y, ldy, mean, invstd, gamma, beta, r, ldr, r_sc, out, ldo, out_sc, M, N);
-    else if (!r_sc) hipLaunchKernelGGL((bn_apply_fwd_pairs_kernel<1>), grid, dim3(256), 0, s, Y, ldy, mean, invstd, gamma, beta, r, ldr, r_sc, out, ldo, out_sc, M, N);
-    else            hipLaunchKernelGGL((bn_apply_fwd_pairs_kernel<2>), grid, dim3(256), 0, s, Y, ldy, mean, invstd, gamma, beta, r, ldr, r_sc, out, ldo, out_sc, M, N);
+    if (!R)        hipLaunchKernelGGL((bn_apply_fwd_pairs_kernel<0>), grid, dim3(PAIRS_WG), 0, s, Y, ldy, mean, invstd, gamma, beta, r, ldr, r_sc, out, ldo, out_sc, M, N);
+    else if (!r_sc) hipLaunchKernelGGL((bn_apply_fwd_pairs_kernel<1>), grid, dim3(PAIRS_WG), 0, s, Y, ldy, mean, invstd, gamma, beta, r, ldr, r_sc, out, ldo, out_sc, M, N);
+    else            hipLaunchKernelGGL((bn_apply_fwd_pairs_kernel<2>), grid, dim3(PAIRS_WG), 0, s, Y, ldy, mean, invstd, gamma, beta, r, ldr, r_sc, out, ldo, out_sc, M, N);
     return check_launch("bn_apply_fwd_pairs");
 }
 
