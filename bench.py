@@ -578,7 +578,8 @@ def main():
     # by events: there the dominant kernel is timed in untimed eager steps right after the timed region instead.
     dominant_flops = 2.0 * (S * B) * 1000 * 1000
     from behavio_temporal_vae_amd import vae_models as VM
-    graphed = (world == 1 and S * B <= VM.STEP_GRAPH_MAX_ROWS and os.environ.get("BTVAE_STEP_GRAPH", "auto") != "0")
+    graph_mode = os.environ.get("BTVAE_STEP_GRAPH", "auto")
+    graphed = world == 1 and graph_mode != "0" and (S * B <= VM.STEP_GRAPH_MAX_ROWS or graph_mode == "1")
     if not graphed:
         nv.prof_filter(["gemm_fwd"], 0.9 * dominant_flops)
         nv.prof_enable(True)
