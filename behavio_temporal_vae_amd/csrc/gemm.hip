@@ -633,6 +633,7 @@ int launch(GemmArgs& a, int splits, hipStream_t s, const char* what, bool reduce
     BTVAE_REQUIRE(!a.b_sc || (AL == LAY_M && BL == LAY_M && EPI == EPI_PLAIN && prec == 3 && a.amax_a && a.b_vec && a.ldb % 16 == 0),
                   "%s: a pair-format B operand belongs to the weight gradients of the two-piece mode (maximum of the other operand given, pitch a multiple of 16)", what);
     const bool two = split && prec == 3 && has_twopiece<AL, BL, EPI>() && a.amax_a && (a.amax_b || a.b_sc);
+    BTVAE_REQUIRE(!a.b_sc || two, "%s: a pair-format B operand needs the two-piece kernel (16-byte addressable operands)", what);
     if ((prec == 3 && !two) || prec == 1) a.Bp = nullptr;        // planes made in these modes hold fp16 pieces / bf16 stage images
     // 128 x 256 block tile: the weight gradients, whose two operands are both split in the kernel (+5-10 %; the products
     // with a pre-split weight gain nothing from it and short reductions lose to its longer epilogue)
