@@ -95,6 +95,7 @@ _SIGS = {
     "btvae_adam_tick": [P, P, I, P],
     "btvae_clip_adam_step_dev": [P, P, P, P, LL, P, P, P, P],
     "btvae_cond_mvn_sample": [P, P, P, P, ULL, P, P, P, P, I, I, I, P],
+    "btvae_cond_mvn_sample_wide": [P, P, P, P, P, P, P, P, P, I, I, I, P],
     "btvae_masked_scatter": [P, P, P, LL, P],
     "btvae_lse_over_k": [P, P, I, I, P],
     "btvae_pack_lower": [P, P, LL, I, P],

@@ -121,13 +121,14 @@ __global__ __launch_bounds__(256) void diag_loglik_kernel(const float* __restric
 // dictionary tables: Uhat = U / ||U[:,v]||, UU[p][v] = Uhat[d,v]*Uhat[e,v] for packed p = d(d+1)/2+e (e<=d),
 // diag[p] = m^2 on the diagonal entries.  Sigma_packed = sigma^2 @ UU^T + diag.
 // ---------------------------------------------------------------------------------------------
-// one wave per dictionary column v: lane d holds U[d][v] (D <= 64)
+// one wave per dictionary column v: lane l holds U[l][v] and U[l + 64][v] (D <= 128)
 __global__ __launch_bounds__(64) void dict_norm_kernel(const float* __restrict__ U, float* __restrict__ Uhat, float* __restrict__ norms, int D, int V) {
-    const int v = blockIdx.x, d = threadIdx.x;
-    const float u = d < D ? U[(size_t)d * V + v] : 0.f;
-    const float n = sqrtf(wave_sum(u * u));
-    if (d == 0) norms[v] = n;
-    if (d < D) Uhat[(size_t)d * V + v] = u / n;
+    const int v = blockIdx.x, d0 = threadIdx.x, d1 = d0 + 64;
+    const float u0 = d0 < D ? U[(size_t)d0 * V + v] : 0.f, u1 = d1 < D ? U[(size_t)d1 * V + v] : 0.f;
+    const float n = sqrtf(wave_sum(u0 * u0 + u1 * u1));
+    if (d0 == 0) norms[v] = n;
+    if (d0 < D) Uhat[(size_t)d0 * V + v] = u0 / n;
+    if (d1 < D) Uhat[(size_t)d1 * V + v] = u1 / n;
 }
 
 __global__ void dict_tables_kernel(const float* __restrict__ Uhat, float* __restrict__ UU, float* __restrict__ diag, int D, int V, float m2) {
@@ -143,25 +144,34 @@ __global__ void dict_tables_kernel(const float* __restrict__ Uhat, float* __rest
     if (v == 0) diag[p] = d == e ? m2 : 0.f;
 }
 
-// dU (+)= d/dU of the likelihood given M1[p][v] = sum_rows Pg[row][p] * sigma^2[row][v]; one wave per column v.
+// dU (+)= d/dU of the likelihood given M1[p][v] = sum_rows Pg[row][p] * sigma^2[row][v]; one wave per column v, lane l
+// holds coordinates l and l + 64.
 __global__ __launch_bounds__(64) void dict_grad_kernel(const float* __restrict__ M1, const float* __restrict__ Uhat,
                                                        const float* __restrict__ norms, float* __restrict__ dU,
                                                        int D, int V, int accumulate) {
-    const int v = blockIdx.x, d = threadIdx.x;
-    float g = 0.f, uh = 0.f;
-    if (d < D) {
-        uh = Uhat[(size_t)d * V + v];
-        for (int e = 0; e < D; ++e) {
-            const int mx = max(d, e), mn = min(d, e);
-            const float pv = M1[(size_t)(mx * (mx + 1) / 2 + mn) * V + v] * (d == e ? 1.f : 0.5f);
-            g += pv * Uhat[(size_t)e * V + v];
+    const int v = blockIdx.x;
+    float g[2] = {0.f, 0.f}, uh[2] = {0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int d = threadIdx.x + 64 * h;
+        if (d < D) {
+            uh[h] = Uhat[(size_t)d * V + v];
+            for (int e = 0; e < D; ++e) {
+                const int mx = max(d, e), mn = min(d, e);
+                const float pv = M1[(size_t)(mx * (mx + 1) / 2 + mn) * V + v] * (d == e ? 1.f : 0.5f);
+                g[h] += pv * Uhat[(size_t)e * V + v];
+            }
         }
     }
-    const float dot = wave_sum(g * uh);
-    if (d < D) {
-        const float out = (g - uh * dot) / norms[v];
-        const size_t o = (size_t)d * V + v;
-        dU[o] = accumulate ? dU[o] + out : out;
+    const float dot = wave_sum(g[0] * uh[0] + g[1] * uh[1]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int d = threadIdx.x + 64 * h;
+        if (d < D) {
+            const float out = (g[h] - uh[h] * dot) / norms[v];
+            const size_t o = (size_t)d * V + v;
+            dU[o] = accumulate ? dU[o] + out : out;
+        }
     }
 }
 
@@ -523,6 +533,90 @@ __global__ __launch_bounds__(64) void mvn_rows_lane_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// MVN rows for 64 < D <= 128: one workgroup per row, the covariance as a full symmetric matrix in LDS (row pitch odd, so a
+// column is read without bank conflicts).  The same symmetric sweep as mvn_rows_kernel<DP, true> -- A <- -Sigma^-1, the
+// pivots are those of LDL^T -- with the pivot column copied out before each step; thread (tid & 127) owns column j of rows
+// tid >> 7, + 2, ...  Outputs and conventions as above (BWD adds dmu_raw and Pg).  Some hundred times slower per row than
+// the register kernels: the reference has no limit on the dimension, the shipped configurations stop at 48.
+// ---------------------------------------------------------------------------------------------
+constexpr int WIDE_D = 128, WIDE_LD = WIDE_D + 1;
+
+// packed index p -> (d, e), e <= d
+__device__ __forceinline__ void unpack_lower(int p, int& d, int& e) {
+    d = (int)((sqrtf(8.f * p + 1.f) - 1.f) * 0.5f);
+    while ((d + 1) * (d + 2) / 2 <= p) ++d;
+    while (d * (d + 1) / 2 > p) --d;
+    e = p - d * (d + 1) / 2;
+}
+
+// one sweep step on pivot k of the D x D matrix A (LDS): col receives the pivot column; returns the pivot
+__device__ __forceinline__ float wide_sweep_step(float* A, float* col, int D, int k, int tid) {
+    __syncthreads();
+    if (tid < D) col[tid] = A[tid * WIDE_LD + k];
+    __syncthreads();
+    const float piv = col[k], rp = 1.f / piv;
+    const int j = tid & 127;
+    if (j < D) {
+        const float cj = col[j];
+        for (int i = tid >> 7; i < D; i += 2) {
+            const float gi = (i == k) ? (1.f - rp) : col[i] * rp;
+            float* a = A + i * WIDE_LD + j;
+            *a = (j == k) ? ((i == k) ? -rp : gi) : fmaf(-gi, cj, *a);
+        }
+    }
+    return piv;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red, int tid) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void mvn_rows_wide_kernel(const float* __restrict__ Sp, const float* __restrict__ mu,
+                                                            const float* __restrict__ x, const float* __restrict__ dfac_mu,
+                                                            const float* __restrict__ g_rows, float g_const,
+                                                            float* __restrict__ logp, float* __restrict__ dmu_raw,
+                                                            float* __restrict__ Pg, int rows, int B, int D) {
+    __shared__ float A[WIDE_D * WIDE_LD];
+    __shared__ float col[WIDE_D], rv[WIDE_D], al[WIDE_D], red[4];
+    const int tid = threadIdx.x, row = blockIdx.x;
+    const int NP = D * (D + 1) / 2;
+    for (int p = tid; p < NP; p += 256) {
+        int d, e;
+        unpack_lower(p, d, e);
+        const float v = Sp[(size_t)row * NP + p];
+        A[d * WIDE_LD + e] = v;
+        A[e * WIDE_LD + d] = v;
+    }
+    if (tid < D) rv[tid] = x[(size_t)(row % B) * D + tid] - mu[(size_t)row * D + tid];
+    float logdet = 0.f;
+    for (int k = 0; k < D; ++k) logdet += logf(wide_sweep_step(A, col, D, k, tid));
+    __syncthreads();
+    // A = -Sigma^-1: alpha_i = -sum_j A[i][j] r_j
+    float alpha = 0.f;
+    if (tid < D) {
+        for (int j = 0; j < D; ++j) alpha = fmaf(-A[tid * WIDE_LD + j], rv[j], alpha);
+        al[tid] = alpha;
+    }
+    const float maha = block_sum_256(tid < D ? rv[tid] * alpha : 0.f, red, tid);
+    if (tid == 0) logp[row] = -0.5f * ((float)D * LOG_2PI + maha) - 0.5f * logdet;
+    if (BWD) {
+        const float g = g_rows ? g_rows[row] : g_const;
+        if (tid < D) dmu_raw[(size_t)row * D + tid] = g * alpha * dfac_mu[(size_t)row * D + tid];
+        for (int p = tid; p < NP; p += 256) {
+            int d, e;
+            unpack_lower(p, d, e);
+            Pg[(size_t)row * NP + p] = g * (al[d] * al[e] + A[d * WIDE_LD + e]) * (d == e ? 1.f : 2.f);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // ELBO scalars: out = [loss, elbo, rll, kl], rll = mean(logp), kl = mean(klrow), loss = -(rll - beta*kl)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void elbo_scalars_kernel(const float* __restrict__ logp, int nlog, const float* __restrict__ klrow,
@@ -611,6 +705,10 @@ template <bool BWD>
 int launch_mvn(int D, const float* Sp, const float* mu, const float* x, const float* dfac_mu, const float* g_rows, float g_const,
                float* logp, float* dmu_raw, float* Pg, int rows, int B, hipStream_t s) {
     dim3 grid((rows + 3) / 4), block(256);
+    if (D > 64) {                                     // one workgroup per row, the matrix in LDS
+        hipLaunchKernelGGL((mvn_rows_wide_kernel<BWD>), dim3(rows), block, 0, s, Sp, mu, x, dfac_mu, g_rows, g_const, logp, dmu_raw, Pg, rows, B, D);
+        return btvae::check_launch("mvn_rows");
+    }
     static const bool no_lane = getenv("BTVAE_MVN_FWD_PAIR") != nullptr;      // A/B switch: the two-rows-per-wave kernel
     if (!BWD && D <= 24 && !no_lane) {
         dim3 lgrid((rows + 63) / 64);
@@ -698,7 +796,7 @@ BTVAE_API int btvae_diag_gauss_loglik(const float* x, const float* mu, const flo
 BTVAE_API int btvae_dict_prepare(const float* U, float* Uhat, float* norms, float* UU, float* diag, int D, int V,
                                  float marginal_std_lim, void* stream) {
     BTVAE_REQUIRE(U && Uhat && norms && UU && diag, "dict_prepare: null pointer");
-    BTVAE_REQUIRE(D > 0 && D <= 64 && V > 0, "dict_prepare: D=%d must be in 1..64", D);
+    BTVAE_REQUIRE(D > 0 && D <= 128 && V > 0, "dict_prepare: D=%d must be in 1..128", D);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(dict_norm_kernel, dim3(V), dim3(64), 0, s, U, Uhat, norms, D, V);
     const size_t n = (size_t)(D * (D + 1) / 2) * V;
@@ -708,7 +806,7 @@ BTVAE_API int btvae_dict_prepare(const float* U, float* Uhat, float* norms, floa
 
 BTVAE_API int btvae_dict_grad(const float* M1, const float* Uhat, const float* norms, float* dU, int D, int V, int accumulate, void* stream) {
     BTVAE_REQUIRE(M1 && Uhat && norms && dU, "dict_grad: null pointer");
-    BTVAE_REQUIRE(D > 0 && D <= 64, "dict_grad: D=%d must be in 1..64", D);
+    BTVAE_REQUIRE(D > 0 && D <= 128, "dict_grad: D=%d must be in 1..128", D);
     hipLaunchKernelGGL(dict_grad_kernel, dim3(V), dim3(64), 0, (hipStream_t)stream, M1, Uhat, norms, dU, D, V, accumulate);
     return check_launch("dict_grad");
 }
@@ -716,7 +814,7 @@ BTVAE_API int btvae_dict_grad(const float* M1, const float* Uhat, const float* n
 // Forward-only MVN log-density of rows given packed covariances Sp[rows, D(D+1)/2].
 BTVAE_API int btvae_mvn_rows_fwd(const float* Sp, const float* mu, const float* x, float* logp, int rows, int B, int D, void* stream) {
     BTVAE_REQUIRE(Sp && mu && x && logp, "mvn_rows_fwd: null pointer");
-    BTVAE_REQUIRE(rows > 0 && B > 0 && D > 0 && D <= 64, "mvn_rows_fwd: bad shape rows=%d B=%d D=%d", rows, B, D);
+    BTVAE_REQUIRE(rows > 0 && B > 0 && D > 0 && D <= 128, "mvn_rows_fwd: bad shape rows=%d B=%d D=%d (D at most 128)", rows, B, D);
     const double np = 0.5 * D * (D + 1);
     ProfScope ps(PK_MVN_ROWS, (hipStream_t)stream, rows * (double)D * D * D / 3.0, 4.0 * rows * (np + D + 1));
     return launch_mvn<false>(D, Sp, mu, x, nullptr, nullptr, 0.f, logp, nullptr, nullptr, rows, B, (hipStream_t)stream);
@@ -726,7 +824,7 @@ BTVAE_API int btvae_mvn_rows_fwd(const float* Sp, const float* mu, const float* 
 BTVAE_API int btvae_mvn_rows_fwd_bwd(const float* Sp, const float* mu, const float* x, const float* dfac_mu, const float* g_rows,
                                      float g_const, float* logp, float* dmu_raw, float* Pg, int rows, int B, int D, void* stream) {
     BTVAE_REQUIRE(Sp && mu && x && dfac_mu && logp && dmu_raw && Pg, "mvn_rows_fwd_bwd: null pointer");
-    BTVAE_REQUIRE(rows > 0 && B > 0 && D > 0 && D <= 64, "mvn_rows_fwd_bwd: bad shape rows=%d B=%d D=%d", rows, B, D);
+    BTVAE_REQUIRE(rows > 0 && B > 0 && D > 0 && D <= 128, "mvn_rows_fwd_bwd: bad shape rows=%d B=%d D=%d (D at most 128)", rows, B, D);
     const double np = 0.5 * D * (D + 1);
     ProfScope ps(PK_MVN_ROWS, (hipStream_t)stream, rows * 2.0 * D * D * D, 4.0 * rows * (2 * np + 3 * D + 1));
     return launch_mvn<true>(D, Sp, mu, x, dfac_mu, g_rows, g_const, logp, dmu_raw, Pg, rows, B, (hipStream_t)stream);

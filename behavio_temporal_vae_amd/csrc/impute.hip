@@ -124,6 +124,85 @@ __global__ __launch_bounds__(256) void cond_mvn_kernel(const float* __restrict__
     if (live && is_un) samp[(size_t)row * U + myu] = sm;
 }
 
+// The same for 64 < D <= 128: one workgroup per profile, the covariance as a full symmetric matrix in LDS (odd row pitch),
+// thread (tid & 127) owns column j of rows tid >> 7, + 2, ...; the observed set as two 64-bit words.  Sweep steps on the
+// observed pivots, then the elimination over the unobserved ones with the draw accumulated per coordinate, as above.
+constexpr int WIDE_D = 128, WIDE_LD = WIDE_D + 1;
+
+__global__ __launch_bounds__(256) void cond_mvn_wide_kernel(const float* __restrict__ Sp, const float* __restrict__ mu,
+                                                            const float* __restrict__ x, const float* __restrict__ eps,
+                                                            unsigned long long obs_lo, unsigned long long obs_hi,
+                                                            const int* __restrict__ un_pos, float* __restrict__ samp,
+                                                            float* __restrict__ cmean, float* __restrict__ ccov, int rows, int D, int U) {
+    __shared__ float A[WIDE_D * WIDE_LD];
+    __shared__ float col[WIDE_D], rv[WIDE_D];
+    __shared__ int up[WIDE_D];
+    const int tid = threadIdx.x, row = blockIdx.x;
+    const int NP = D * (D + 1) / 2;
+    auto observed = [&](int d) { return (((d < 64 ? obs_lo : obs_hi) >> (d & 63)) & 1ull) != 0; };
+    for (int p = tid; p < NP; p += 256) {
+        int d = (int)((sqrtf(8.f * p + 1.f) - 1.f) * 0.5f);
+        while ((d + 1) * (d + 2) / 2 <= p) ++d;
+        while (d * (d + 1) / 2 > p) --d;
+        const int e = p - d * (d + 1) / 2;
+        const float v = Sp[(size_t)row * NP + p];
+        A[d * WIDE_LD + e] = v;
+        A[e * WIDE_LD + d] = v;
+    }
+    const bool mine = tid < D;
+    const bool is_obs = mine && observed(tid), is_un = mine && !is_obs;
+    const float mui = mine ? mu[(size_t)row * D + tid] : 0.f;
+    if (mine) {
+        rv[tid] = is_obs ? x[(size_t)row * D + tid] - mui : 0.f;      // residual of the observed coordinates
+        up[tid] = un_pos[tid];
+    }
+    const int j = tid & 127;
+    // symmetric sweep on the observed pivots
+    for (int k = 0; k < D; ++k) {
+        if (!observed(k)) continue;                     // uniform
+        __syncthreads();
+        if (mine) col[tid] = A[tid * WIDE_LD + k];
+        __syncthreads();
+        const float rp = 1.f / col[k];
+        if (j < D) {
+            const float cj = col[j];
+            for (int i = tid >> 7; i < D; i += 2) {
+                const float gi = (i == k) ? (1.f - rp) : col[i] * rp;
+                float* a = A + i * WIDE_LD + j;
+                *a = (j == k) ? ((i == k) ? -rp : gi) : fmaf(-gi, cj, *a);
+            }
+        }
+    }
+    __syncthreads();
+    // A[u][o] = (Sigma_uo Sigma_oo^-1)[u][o], A[u][u'] = conditional covariance
+    float cm = mui;
+    if (is_un) {
+        for (int k = 0; k < D; ++k)
+            if (observed(k)) cm = fmaf(A[tid * WIDE_LD + k], rv[k], cm);
+        cmean[(size_t)row * U + up[tid]] = cm;
+    }
+    if (j < D && !observed(j))
+        for (int i = tid >> 7; i < D; i += 2)
+            if (!observed(i)) ccov[((size_t)row * U + up[i]) * U + up[j]] = A[i * WIDE_LD + j];
+    // draw: forward elimination over the unobserved pivots, sample_i = cm_i + sum_k L[i][k] sqrt(d_k) eps_k
+    float sm = cm;
+    for (int k = 0; k < D; ++k) {
+        if (observed(k)) continue;                      // uniform
+        __syncthreads();
+        if (mine) col[tid] = A[tid * WIDE_LD + k];
+        __syncthreads();
+        const float piv = col[k], rp = 1.f / piv;
+        const float ek = eps[(size_t)row * U + up[k]] * sqrtf(piv);
+        if (is_un && tid >= k) sm = fmaf(tid == k ? 1.f : col[tid] * rp, ek, sm);
+        if (j < D && j > k) {
+            const float cj = col[j];
+            for (int i = (tid >> 7) + k + 1; i < D; i += 2)
+                if (!observed(i)) A[i * WIDE_LD + j] = fmaf(-col[i] * rp, cj, A[i * WIDE_LD + j]);
+        }
+    }
+    if (is_un) samp[(size_t)row * U + up[tid]] = sm;
+}
+
 __global__ void masked_scatter_kernel(float* __restrict__ dst, const long long* __restrict__ idx, const float* __restrict__ src, long long n) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) dst[idx[t]] = src[t];
@@ -181,6 +260,31 @@ BTVAE_API int btvae_cond_mvn_sample(const float* Sp, const float* mu, const floa
     else BTVAE_COND_CASE(64);
 #undef BTVAE_COND_CASE
     return check_launch("cond_mvn_sample");
+}
+
+// The same for D up to 128: the observed set as two 64-bit words (host array; bit d of word d / 64 = coordinate d observed).
+BTVAE_API int btvae_cond_mvn_sample_wide(const float* Sp, const float* mu, const float* x, const float* eps, const unsigned long long* obs_mask2,
+                                         const int* un_pos, float* samples, float* cond_mean, float* cond_cov, int rows, int D, int U,
+                                         void* stream) {
+    BTVAE_REQUIRE(obs_mask2, "cond_mvn_sample_wide: null mask");
+    if (D <= 64) {
+        BTVAE_REQUIRE(obs_mask2[1] == 0, "cond_mvn_sample_wide: mask names coordinates beyond D=%d", D);
+        return btvae_cond_mvn_sample(Sp, mu, x, eps, obs_mask2[0], un_pos, samples, cond_mean, cond_cov, rows, D, U, stream);
+    }
+    BTVAE_REQUIRE(Sp && mu && x && eps && un_pos && samples && cond_mean && cond_cov, "cond_mvn_sample_wide: null pointer");
+    BTVAE_REQUIRE(rows > 0 && D <= 128 && U > 0 && U <= D, "cond_mvn_sample_wide: bad shape rows=%d D=%d U=%d (D at most 128)", rows, D, U);
+    int nobs = 0;
+    for (int d = 0; d < 128; ++d) {
+        const int bit = (int)((obs_mask2[d >> 6] >> (d & 63)) & 1ull);
+        BTVAE_REQUIRE(!bit || d < D, "cond_mvn_sample_wide: mask names coordinate %d beyond D=%d", d, D);
+        nobs += bit;
+    }
+    BTVAE_REQUIRE(nobs == D - U, "cond_mvn_sample_wide: mask has %d observed coordinates, expected %d", nobs, D - U);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PK_MVN_ROWS, s, rows * 2.0 * D * D * D, 4.0 * rows * (0.5 * D * (D + 1) + 2.0 * D + U * (U + 3.0)));
+    hipLaunchKernelGGL(cond_mvn_wide_kernel, dim3(rows), dim3(256), 0, s, Sp, mu, x, eps, obs_mask2[0], obs_mask2[1], un_pos, samples, cond_mean,
+                       cond_cov, rows, D, U);
+    return check_launch("cond_mvn_sample_wide");
 }
 
 // dst[idx[t]] = src[t], t < n: the row-major masked write-back of a Gibbs sweep.

@@ -13,6 +13,7 @@ to all rows, src/imputation_lib.py:89), and the Normal-decoder conditional uses 
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import time
 
@@ -72,8 +73,13 @@ def _cond_rows(model, mu, sigma, x_full, eps, split):
     Sp = E.dict_covariance_packed(tab, (sigma * sigma).contiguous())
     samp, mean = torch.empty(rows, U, device=dev), torch.empty(rows, U, device=dev)
     cov = torch.empty(rows, U, U, device=dev)
-    nv.call("btvae_cond_mvn_sample", nv.ptr(Sp), nv.ptr(mu), nv.ptr(x_full), nv.ptr(eps), split.mask, nv.ptr(split.un_pos), nv.ptr(samp),
-            nv.ptr(mean), nv.ptr(cov), rows, D, U)
+    if D <= 64:
+        nv.call("btvae_cond_mvn_sample", nv.ptr(Sp), nv.ptr(mu), nv.ptr(x_full), nv.ptr(eps), split.mask, nv.ptr(split.un_pos), nv.ptr(samp),
+                nv.ptr(mean), nv.ptr(cov), rows, D, U)
+    else:                                             # the observed set as two 64-bit words
+        words = (ctypes.c_ulonglong * 2)(split.mask & (2 ** 64 - 1), split.mask >> 64)
+        nv.call("btvae_cond_mvn_sample_wide", nv.ptr(Sp), nv.ptr(mu), nv.ptr(x_full), nv.ptr(eps), ctypes.cast(words, ctypes.c_void_p),
+                nv.ptr(split.un_pos), nv.ptr(samp), nv.ptr(mean), nv.ptr(cov), rows, D, U)
     return samp, mean, cov
 
 

@@ -219,8 +219,8 @@ class DictionaryGaussian(torch.nn.Module):
         super().__init__()
         if vocab_size <= output_dim:
             raise ValueError("Vocabulary size should be larger than the output dimension. Please increase the vocabulary size.")
-        if output_dim > 64:
-            raise ValueError("The HIP dictionary-Gaussian kernels support output_dim <= 64.")
+        if output_dim > 128:
+            raise ValueError("The HIP dictionary-Gaussian kernels support output_dim <= 128 (registers up to 64, LDS beyond).")
         self.vocab_size, self.marginal_std_lim, self.output_dim = vocab_size, marginal_std_lim, output_dim
         self.input_dim = input_dim
         self.mu_upper_lim, self.mu_lower_lim = mu_upper_lim, mu_lower_lim

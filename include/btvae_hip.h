@@ -321,7 +321,9 @@ int btvae_diag_gauss_loglik(const float* x, const float* mu, const float* sigma,
                             const float* dfac_sigma, float* draw_mu, float* draw_sigma, const float* g_rows, float g_const,
                             int rows, int B, int D, void* stream);
 /* Uhat = U/||U[:,v]|| (src/utils.py:18-19), UU[p][v] = Uhat[d,v]*Uhat[e,v] for packed p=d(d+1)/2+e, diag[p] = m^2
- * on diagonal entries. D <= 64. */
+ * on diagonal entries.  D <= 128 here and in the three entry points below: up to 64 the per-row kernels hold the covariance
+ * in registers, one wave (or lane) per row; beyond that one workgroup per row works on it in LDS, far slower per row (the
+ * reference, src/submodels.py:169-179, has no limit; its shipped configurations stop at 48). */
 int btvae_dict_prepare(const float* U, float* Uhat, float* norms, float* UU, float* diag, int D, int V,
                        float marginal_std_lim, void* stream);
 /* dU (+)= gradient of the dictionary from M1[p][v] = sum_rows Pg[row][p]*sigma^2[row][v]. */
@@ -354,10 +356,15 @@ int btvae_clip_adam_step_dev(float* p, const float* g, float* m, float* v, long 
                              const float* hyper, float* norm_out, void* stream);
 int btvae_scale(float* x, long long n, float a, void* stream);
 
-/* ---- conditional imputation (src/imputation_lib.py:16-57,92,230-231) ---- */
+/* ---- conditional imputation (src/imputation_lib.py:16-57,92,230-231) ----
+ * btvae_cond_mvn_sample: D <= 64, bit d of obs_mask = coordinate d observed.  btvae_cond_mvn_sample_wide: D <= 128, the
+ * observed set as a host array of two 64-bit words (bit d % 64 of word d / 64); up to 64 it forwards to the first. */
 int btvae_cond_mvn_sample(const float* Sp, const float* mu, const float* x, const float* eps, unsigned long long obs_mask,
                           const int* un_pos, float* samples, float* cond_mean, float* cond_cov, int rows, int D, int U,
                           void* stream);
+int btvae_cond_mvn_sample_wide(const float* Sp, const float* mu, const float* x, const float* eps, const unsigned long long* obs_mask2,
+                               const int* un_pos, float* samples, float* cond_mean, float* cond_cov, int rows, int D, int U,
+                               void* stream);
 int btvae_masked_scatter(float* dst, const long long* idx, const float* src, long long n, void* stream);
 int btvae_lse_over_k(const float* logp, float* out, int K, int B, void* stream);
 int btvae_pack_lower(const float* full, float* packed, long long rows, int D, void* stream);

@@ -837,8 +837,9 @@ def test_reparam_kl(dev, threeD):
 
 
 @pytest.mark.parametrize("D,V,rows,B", [(48, 100, 301, 43), (6, 9, 50, 10), (24, 100, 130, 130), (64, 70, 37, 37), (2, 3, 5, 1), (33, 40, 4, 4),
-                                         (12, 20, 70, 7), (30, 35, 66, 66)])
+                                         (12, 20, 70, 7), (30, 35, 66, 66), (65, 30, 21, 7), (96, 120, 70, 35), (128, 60, 9, 9)])
 def test_dictgauss_mvn(dev, D, V, rows, B):
+    """Dimensions up to 64 run on the register kernels, beyond that (65, 96, 128) on the one-workgroup-per-row LDS kernels."""
     U = rnd(D, V, seed=1)
     sig = (rnd(rows, V, seed=2).abs() * 0.3 + 1e-3).clamp(max=0.62)
     mu, x = rnd(rows, D, seed=3), rnd(B, D, seed=4)
@@ -954,7 +955,11 @@ def test_clip_adam(dev):
 @pytest.mark.parametrize("rows,D,obs", [(70, 48, list(range(0, 12)) + list(range(36, 48))),     # a non-suffix window
                                         (5, 64, list(range(1, 64, 2))),                          # largest dimension, interleaved
                                         (9, 7, [6]),                                             # one observed coordinate
-                                        (3, 24, list(range(23)))])                               # one unobserved coordinate
+                                        (3, 24, list(range(23))),                                # one unobserved coordinate
+                                        (11, 96, list(range(0, 96, 2))),                         # beyond 64: the LDS kernel, two mask words
+                                        (4, 128, list(range(60, 128))),                          # observed block across the word boundary
+                                        (5, 65, [64]),                                           # one observed coordinate, in the second word
+                                        (6, 40, list(range(0, 40, 3)))])                         # the two-word entry point forwarding to the register kernel
 def test_cond_mvn(dev, rows, D, obs):
     Uc = D - len(obs)
     NP = D * (D + 1) // 2
@@ -971,7 +976,13 @@ def test_cond_mvn(dev, rows, D, obs):
         un_pos[i] = r_
     samp, cm, cc = torch.empty(rows, Uc, device=dev), torch.empty(rows, Uc, device=dev), torch.empty(rows, Uc, Uc, device=dev)
     mud, xd, epsd, upd = mu.to(dev), x.to(dev), eps.to(dev), un_pos.to(dev)
-    nv.call("btvae_cond_mvn_sample", P(Sp), P(mud), P(xd), P(epsd), mask, P(upd), P(samp), P(cm), P(cc), rows, D, Uc)
+    if D > 64 or D == 40:
+        import ctypes
+        words = (ctypes.c_ulonglong * 2)(mask & (2 ** 64 - 1), mask >> 64)
+        nv.call("btvae_cond_mvn_sample_wide", P(Sp), P(mud), P(xd), P(epsd), ctypes.cast(words, ctypes.c_void_p), P(upd), P(samp), P(cm), P(cc),
+                rows, D, Uc)
+    else:
+        nv.call("btvae_cond_mvn_sample", P(Sp), P(mud), P(xd), P(epsd), mask, P(upd), P(samp), P(cm), P(cc), rows, D, Uc)
     S64 = Sp.cpu().double()
     full = torch.zeros(rows, D, D, dtype=torch.float64)
     full[:, tri[0], tri[1]] = S64

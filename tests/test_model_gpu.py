@@ -919,3 +919,56 @@ def test_two_piece_guard_raises_on_overflow(dev):
     with pytest.raises(RuntimeError, match="non-finite accumulators"):
         E.GUARD.check()
     E.GUARD.reset()
+
+
+def test_dict_gauss_beyond_64_dimensions(dev):
+    """A dictionary-Gaussian decoder with 96 output coordinates (the reference has no limit on the dimension,
+    src/submodels.py:169-179; up to 64 the covariance rows live in registers, beyond that in LDS, one workgroup per row):
+    one train step, the importance-weighted score and the imputation conditional against the fp64 oracle at 1e-4."""
+    import contextlib, io
+    from oracle import refimpl as R
+    from behavio_temporal_vae_amd.vae_models import CVAE
+    from behavio_temporal_vae_amd import testing_lib, imputation_lib
+    D, C, L, B, S, K = 96, 4, 12, 40, 3, 5
+    cfg = {"latent_dim": L, "distribution_dict": {
+        "posterior": {"dist_type": "normal", "sigma_lim": 0.05, "mu_upper_lim": 5.0, "mu_lower_lim": -5.0, "num_neurons": 72,
+                      "num_hidden_layers": 2, "dropout": False, "batch_normalization": True},
+        "likelihood": {"dist_type": "dict-gauss", "vocab_size": 128, "sigma_lim": 1e-6, "marginal_std_lim": 0.05, "mu_lower_lim": -3,
+                       "num_neurons": 72, "num_hidden_layers": 2, "dropout": False, "batch_normalization": True}}}
+    torch.manual_seed(11)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = CVAE(input_dim=D, conditioner=Cdim(C), **cfg)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(B, D, generator=gen).mul_(0.7).add_(0.5)
+    c = torch.randn(B, C, generator=gen)
+    eps = torch.randn(S, B, L, generator=gen)
+    spec = R.model_spec(D, C, cfg)
+    sd64 = R.cast_state({k: v.clone() for k, v in sd0.items()}, torch.float64)
+    terms, grads, norm = R.train_step(dict(sd64), spec, None, x.double(), c.double(), eps.double(), lr=0.0, weight_decay=0.0, beta=1.0,
+                                      max_norm=None, optimizer="sgd")
+    m = m.to(dev).train()
+    xd, cd = x.to(dev), c.to(dev)
+    fw = m._run_forward(xd, cd, S, eps=eps.to(dev), tape=True)
+    out = m._loss_and_backward(fw, xd, 1.0).tolist()
+    for v, k in zip(out, ("loss", "elbo", "rll", "kl")):
+        assert abs(v - terms[k]) <= 1e-4 * abs(terms[k]), (k, v, terms[k])
+    gn = float(m._grad_arena.double().pow(2).sum().sqrt())
+    assert abs(gn - norm) <= 1e-3 * norm, (gn, norm)
+    gU = dict(m.named_parameters())["decoder.SigmaMapper"].grad.double().cpu()
+    assert float((gU - grads["decoder.SigmaMapper"]).norm() / grads["decoder.SigmaMapper"].norm()) <= 1e-3
+    # eval mode: K-sample score and the conditional of 37 missing coordinates
+    m.load_state_dict(sd0)
+    m.eval()
+    epsk = torch.randn(K, B, L, generator=gen)
+    ll, rlls, _ = testing_lib.iw_loglikelihood_device(m, xd, cd, K, mc_sample_batch_size=2, eps=epsk.to(dev), return_rlls=True)
+    ll64, rl64, _ = R.iw_loglikelihood(sd64, spec, x.double(), c.double(), epsk.double())
+    assert torch.allclose(rlls.cpu().double(), rl64, rtol=1e-4, atol=1e-4 * float(rl64.abs().max()))
+    assert torch.allclose(ll.cpu().double(), ll64, rtol=1e-4, atol=1e-4 * float(ll64.abs().max()))
+    obs = [i for i in range(D) if i % 5 != 2 and not 60 <= i < 78]
+    lik64, _, _ = R.cvae_forward(sd64, spec, x.double(), c.double(), epsk[:1].double(), False)
+    mean64, cov64 = R.conditional_params(sd64["decoder.SigmaMapper"], spec.dec, lik64["mu"][0], lik64["sigma"][0], x.double()[:, obs], obs)
+    params = {k: v[0].float().to(dev) for k, v in lik64.items()}
+    mean, cov = imputation_lib.get_conditional_params(m.decoder, params, xd[:, obs], torch.tensor(obs))
+    assert torch.allclose(mean.cpu().double(), mean64, rtol=2e-4, atol=2e-4 * float(mean64.abs().max()))
+    assert torch.allclose(cov.cpu().double(), cov64, rtol=2e-4, atol=2e-5 * float(cov64.abs().max()))
