@@ -4,6 +4,7 @@
 // Cross-workgroup reductions go through small partial arrays finished in fp64 by one thread per
 // column, so results are deterministic (no float atomics).
 #include "common.h"
+#include <atomic>
 #include "pairs.h"
 #include <algorithm>
 
@@ -783,18 +784,18 @@ constexpr long long NOALLOC_SCRATCH_FLOATS = 1LL << 20;          // 256 row chun
 }
 static __device__ __align__(256) float scratch[NOALLOC_SCRATCH_FLOATS];
 namespace {
-float* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};                  // per device: that device's address of `scratch`
+std::atomic<float*> g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};     // per device: that device's address of `scratch` (set once by btvae_init, read by any thread)
 }
 
 namespace btvae {
 // Resolve the device address of `scratch` on the CURRENT device (btvae_init calls this with `device` selected).
 int noalloc_scratch_setup(int device) {
     BTVAE_REQUIRE(device >= 0 && device < NOALLOC_MAX_DEVICES, "noalloc scratch: device %d beyond the %d this library tracks", device, NOALLOC_MAX_DEVICES);
-    if (g_scratch_ptr[device]) return 0;
+    if (g_scratch_ptr[device].load(std::memory_order_acquire)) return 0;
     float* ptr = nullptr;
     hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
     BTVAE_REQUIRE(e == hipSuccess && ptr != nullptr, "noalloc scratch: hipGetSymbolAddress failed on device %d: %s", device, hipGetErrorString(e));
-    g_scratch_ptr[device] = ptr;
+    g_scratch_ptr[device].store(ptr, std::memory_order_release);
     return 0;
 }
 }  // namespace btvae
@@ -818,7 +819,7 @@ BTVAE_API int btvae_colsum_noalloc(const float* G, float* out, float* cur, int M
     hipError_t e = hipGetDevice(&dev);
     BTVAE_REQUIRE(e == hipSuccess, "colsum_noalloc: no current device (%s)", hipGetErrorString(e));
     BTVAE_REQUIRE(dev >= 0 && dev < NOALLOC_MAX_DEVICES, "colsum_noalloc: current device %d beyond the %d this library tracks", dev, NOALLOC_MAX_DEVICES);
-    float* ptr = g_scratch_ptr[dev];
+    float* ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
     BTVAE_REQUIRE(ptr != nullptr, "colsum_noalloc: btvae_init(%d) has not run on the current device", dev);
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PK_BN, s, 0, 4.0 * M * N);

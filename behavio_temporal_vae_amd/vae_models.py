@@ -505,6 +505,17 @@ class VAE(torch.nn.Module):
                 if b > a:
                     self._dp_sync.launch(self._grad_arena[a:b])
 
+    def sync_gradients(self):
+        """Data parallelism with the module-level idiom of the reference (forward, loss, ``loss.backward()``, optimiser
+        step: src/vae_models.py:319-324): call between ``backward()`` and the optimiser step.  Averages the whole gradient
+        arena over the ranks of ``enable_data_parallel`` (one all-reduce; nothing overlaps, autograd has finished).
+        ``train_core`` reduces its own gradients and does not need this; without data parallelism it does nothing."""
+        if not self._dp_active:
+            return
+        self._dp_sync.launch(self._grad_arena)
+        self._dp_sync.finish()
+        nv.call("btvae_scale", nv.ptr(self._grad_arena), self._grad_arena.numel(), 1.0 / self._dp_world)
+
     def _dp_finish(self, scalars: torch.Tensor):
         if not self._dp_active:
             return scalars

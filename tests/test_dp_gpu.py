@@ -52,7 +52,7 @@ def _worker(rank, world, port, q):
         B = g["steps_x"].shape[1]
         lo, hi = rank * B // world, (rank + 1) * B // world
         out = {}
-        for mode in ("single", "sync", "per_rank"):
+        for mode in ("single", "sync", "per_rank", "per_rank_module_idiom"):
             m = _build(g, dev)
             if mode != "single":
                 m.enable_data_parallel(sync_batchnorm=(mode == "sync"))
@@ -62,6 +62,19 @@ def _worker(rank, world, port, q):
                 x, c, eps = T(g["steps_x"][t]), T(g["steps_c"][t]), T(g["steps_eps"][t])
                 if mode != "single":
                     x, c, eps = x[lo:hi].contiguous(), c[lo:hi].contiguous(), eps[:, lo:hi].contiguous()
+                if mode == "per_rank_module_idiom":
+                    # the reference's idiom on the module-level API: autograd fills the gradient arena, the caller averages it
+                    from test_model_gpu import _FixedRandn
+                    m.prior_params = {k: v.to(dev) for k, v in m.prior_params.items()}
+                    with _FixedRandn(eps):
+                        xd, zd = m(x, c, num_mc_samples=eps.shape[0])
+                    opt.zero_grad(set_to_none=True)
+                    l = m.loss(x, xd["params"], zd["params"], beta=0.7, prior_params=m.prior_params)
+                    l["loss"].backward()
+                    m.sync_gradients()
+                    opt.step(max_norm=1.0)
+                    losses.append([l[k].item() for k in ("loss", "elbo", "rll", "kl")])
+                    continue
                 l = m._train_step(x, c, opt, eps=eps)
                 losses.append([l[k].item() for k in ("loss", "elbo", "rll", "kl")])
             sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if v.is_floating_point()}
@@ -139,7 +152,12 @@ def test_syncbn_two_ranks_equal_single_device():
     for rank, out, _ in res:
         single_l, single_sd = out["single"]
         sync_l, sync_sd = out["sync"]
-        per_l, _ = out["per_rank"]
+        per_l, per_sd = out["per_rank"]
+        # the module-level idiom with sync_gradients() lands on the weights of the fused data-parallel step
+        _, idiom_sd = out["per_rank_module_idiom"]
+        for k, v in per_sd.items():
+            if "running_" not in k:               # BatchNorm running statistics are per rank in both runs
+                assert np.abs(idiom_sd[k] - v).max() <= 5e-4 * (np.abs(v).max() + 1e-6), k
         # the single-device run is itself pinned to the reference
         assert np.max(np.abs(single_l - g["steps_losses"]) / (np.abs(g["steps_losses"]) + 1e-6)) < 1e-4
         assert np.max(np.abs(sync_l - single_l) / (np.abs(single_l) + 1e-6)) < 1e-4, (rank, sync_l, single_l)
@@ -153,6 +171,9 @@ def test_syncbn_two_ranks_equal_single_device():
         for k, v in psd.items():
             assert np.abs(qsd[k] - v).max() <= 5e-4 * (np.abs(v).max() + 1e-6), k
     assert np.array_equal(res[0][1]["sync"][0], res[1][1]["sync"][0])        # both ranks report the same averaged terms
+    for k, v in res[0][1]["per_rank_module_idiom"][1].items():               # averaged gradients: both ranks hold the same weights
+        if "running_" not in k:
+            assert np.array_equal(v, res[1][1]["per_rank_module_idiom"][1][k]), k
     # K-sharded scoring == unsharded == the reference's golden ll on every rank; the ranks' draw ranges tile K
     gs = load_golden("scoring_tiny")
     rl = np.zeros_like(gs["rlls"])
